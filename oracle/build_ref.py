@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""oracle/build_ref.py -- TEST INFRASTRUCTURE ONLY.
+
+Builds the reference C++ `ugs_sampler` pybind11 module from the sources where they lie under
+/root/reference/src/samplers/ugs_sampler (see oracle/ref_unity.cpp for the recipe and the one
+allocator-flag deviation) into oracle/_ref/.  Nothing from the reference is copied into the repo;
+oracle/_ref/ is git-ignored.  The reference's own build system (setup.py / ninja) is not run: this
+is one direct g++ invocation.
+
+The built module is used only
+  * by tests/ and tools under oracle/ to pin the C restatement (oracle/ugs_oracle.c) and to generate
+    the golden fixtures under tests/golden/ (oracle/make_golden.py), and
+  * optionally by bench.py's `cpu_baseline` leg (kind "reference").
+It is never imported by the product package.
+"""
+import os
+import subprocess
+import sys
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/src/samplers/ugs_sampler"
+OUT_DIR = os.path.join(HERE, "_ref")
+OUT = os.path.join(OUT_DIR, "ugs_sampler" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build(force: bool = False) -> str:
+    if not os.path.isdir(REF):
+        raise FileNotFoundError(f"{REF} not present (the reference does not travel to the GPU box)")
+    srcs = [os.path.join(HERE, "ref_unity.cpp")] + [
+        os.path.join(REF, "src", f)
+        for f in ("preproc.cpp", "sampler.cpp", "ugs_sampler_batch_extension.cpp", "extension.cpp")
+    ] + [os.path.join(REF, "include", f) for f in ("sampler.hpp", "cache.hpp")]
+    if not force and os.path.exists(OUT) and all(
+        os.path.getmtime(OUT) >= os.path.getmtime(s) for s in srcs
+    ):
+        return OUT
+    import pybind11
+    import torch
+    from torch.utils import cpp_extension as ce
+
+    os.makedirs(OUT_DIR, exist_ok=True)
+    cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-w",
+           "-DTORCH_EXTENSION_NAME=ugs_sampler", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           f"-I{REF}", f"-I{REF}/include"]
+    for p in ce.include_paths():
+        cmd.append(f"-I{p}")
+    cmd += [f"-I{pybind11.get_include()}", f"-I{sysconfig.get_paths()['include']}"]
+    cmd += [os.path.join(HERE, "ref_unity.cpp"), "-o", OUT]
+    for p in ce.library_paths():
+        cmd += [f"-L{p}", f"-Wl,-rpath,{p}"]
+    cmd += ["-lc10", "-ltorch", "-ltorch_cpu", "-ltorch_python"]
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+def load():
+    """Import the built reference module under the private name `ugs_sampler` (spec-loaded, not on sys.path)."""
+    import importlib.util
+
+    import torch  # noqa: F401  (libtorch must be loaded before the extension)
+
+    path = OUT
+    if not os.path.exists(path):
+        path = build()
+    spec = importlib.util.spec_from_file_location("ugs_sampler", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))
