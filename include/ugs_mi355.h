@@ -1,0 +1,130 @@
+/* ugs_mi355.h -- C ABI of libugs_mi355.so, the MI355X-native (gfx950 / HIP) uniform k-subgraph sampler.
+ *
+ * This is the drop-in boundary for the reference's `ugs_sampler` plugin (AniruddhaMandal/SS-GNN,
+ * src/samplers/ugs_sampler).  The reference exposes a pybind11 module (src/extension.cpp:4-13) taking
+ * torch::Tensor arguments; this library exposes the same operations over plain pointers and sizes so
+ * that any host language can bind them (ctypes stub: ss-gnn_amd/ugs_sampler/__init__.py; see
+ * INTEGRATION.md).  No torch types appear in any signature.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative UGS_E_* code; ugs_last_error() returns the
+ *     message of the calling thread's last failure (same text as the reference's exception where the
+ *     reference has one).
+ *   - `edge_index` is int64 [2, E] with explicit row stride (elements) so non-contiguous tensors need no copy:
+ *     source of column j = edge_index[j], destination = edge_index[row_stride + j].
+ *   - all outputs are int64, caller-allocated; `dst_is_device` != 0 means the output pointers are
+ *     device (HBM) pointers, otherwise host pointers (pinned or pageable).
+ *   - sampling always runs on the GPU: there is no CPU fallback.  Without a usable HIP device every
+ *     sampling entry point fails with UGS_E_NO_DEVICE.
+ */
+#ifndef UGS_MI355_H
+#define UGS_MI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UGS_OK 0
+#define UGS_E_INVALID_HANDLE (-1)   /* "Invalid preproc handle"            reference src/sampler.cpp:105 */
+#define UGS_E_NO_ROOTS (-2)         /* "No viable roots available"         reference src/sampler.cpp:149 */
+#define UGS_E_BAD_MODE (-3)         /* "mode must be one of: ..."          reference src/ugs_sampler_batch_extension.cpp:89-90 */
+#define UGS_E_BAD_ARG (-4)
+#define UGS_E_NO_DEVICE (-5)        /* no usable HIP device / kernel image */
+#define UGS_E_HIP (-6)              /* a HIP runtime call failed */
+#define UGS_E_UNSUPPORTED (-7)      /* outside the limits documented in DESIGN.md (k > 32, nnz >= 2^31 per plan, ...) */
+#define UGS_E_EDGE_SRC (-8)         /* edge_src range check                reference src/ugs_sampler_batch_extension.cpp:213-222 */
+
+/* edge_mode of sample()            reference src/sampler.cpp:95 ("local" | "flat" | "global") */
+#define UGS_EDGE_LOCAL 0
+#define UGS_EDGE_FLAT 1
+#define UGS_EDGE_GLOBAL 2
+/* mode of sample_batch()           reference src/ugs_sampler_batch_extension.cpp:81 ("sample" | "graph" | "global") */
+#define UGS_MODE_SAMPLE 0
+#define UGS_MODE_GRAPH 1
+#define UGS_MODE_GLOBAL 2
+
+const char *ugs_last_error(void);
+const char *ugs_version(void);
+
+/* Number of usable HIP devices (0 is an error: UGS_E_NO_DEVICE). */
+int ugs_device_count(int *count);
+/* Select the HIP device used by the calling thread's subsequent calls (default: current HIP device). */
+int ugs_set_device(int device);
+
+/* ---- preprocessing handles: replaces create_preproc / destroy_preproc / has_graphlets / get_preproc_info
+ *      (reference src/preproc.cpp:262-314, pybind names src/extension.cpp:7-10) -------------------------------- */
+int ugs_create_preproc(const int64_t *edge_index, int64_t row_stride, int64_t num_cols, int64_t num_nodes, int k,
+                       int64_t *handle_out);
+int ugs_destroy_preproc(int64_t handle);                       /* unknown handles are ignored, like the reference */
+int ugs_has_graphlets(int64_t handle, int *out);               /* unknown handle -> 0 */
+int ugs_get_preproc_info(int64_t handle, int *found, int64_t *num_nodes, int64_t *num_edges_stored, double *Z,
+                         int *bucket_count_nonzero);
+/* internals of a handle for the preprocessing parity tests (any pointer may be NULL):
+ * indptr int64[n+1], indices int32[nnz], edge_col int32[nnz], order int32[n], index_of int32[n],
+ * suffix_deg int32[n], bucket_b double[n], prob double[n], alias int32[n] */
+int ugs_preproc_dump(int64_t handle, int64_t *indptr, int32_t *indices, int32_t *edge_col, int32_t *order,
+                     int32_t *index_of, int32_t *suffix_deg, double *bucket_b, double *prob, int32_t *alias);
+
+/* ---- sample(): replaces sample(handle, m_per_graph, k, edge_mode, base_offset, seed)
+ *      (reference src/sampler.cpp:91-290).  Two phases so that the caller owns the outputs:
+ *      begin  runs the walks on the GPU and reports the number of edge entries;
+ *      finish writes nodes[m,k], edge_index[2,total_edges], edge_ptr[m+1], edge_src[total_edges] and frees the job.
+ *      ugs_job_cancel frees a job that will not be finished. ------------------------------------------------- */
+typedef struct ugs_job ugs_job;
+int ugs_sample_begin(int64_t handle, int m_per_graph, int k, int edge_mode, int64_t base_offset, int seed,
+                     ugs_job **job_out, int64_t *total_edges_out);
+int ugs_sample_finish(ugs_job *job, int64_t *nodes, int64_t *edge_index, int64_t *edge_ptr, int64_t *edge_src,
+                      int dst_is_device);
+
+/* ---- sample_batch(): replaces sample_batch(edge_index, ptr, m_per_graph, k, mode, seed)
+ *      (reference src/ugs_sampler_batch_extension.cpp:77-299), including its process-global LRU of
+ *      preprocessing handles keyed by an FNV-1a hash that ignores k (include/cache.hpp:81-109).
+ *      finish writes nodes[G*m,k], edge_index[2,total_edges], edge_ptr[G*m+1], sample_ptr[G+1],
+ *      edge_src_global[total_edges]. ----------------------------------------------------------------------- */
+int ugs_sample_batch_begin(const int64_t *edge_index, int64_t row_stride, int64_t num_cols, const int64_t *ptr,
+                           int64_t num_graphs, int m_per_graph, int k, int mode, int seed, ugs_job **job_out,
+                           int64_t *total_edges_out);
+int ugs_sample_batch_finish(ugs_job *job, int64_t *nodes, int64_t *edge_index, int64_t *edge_ptr,
+                            int64_t *sample_ptr, int64_t *edge_src_global, int dst_is_device);
+int ugs_job_cancel(ugs_job *job);
+
+/* LRU of preprocessing handles used by ugs_sample_batch_* (capacity from UGS_CACHE_SIZE, default 1000;
+ * reference src/ugs_sampler_batch_extension.cpp:15-38).  Clearing it is the equivalent of a fresh process. */
+int ugs_cache_clear(void);
+int ugs_cache_stats(int64_t *size, int64_t *hits, int64_t *misses);
+
+/* ---- device-resident plans: the batch (or single graph) preprocessed once and kept in HBM, sampled many times,
+ *      optionally over a sub-range of the G*m result rows (multi-GPU sharding: row b = g*m + i depends only on
+ *      (graph g, seed, i)).  All pointers passed to walk/fill are DEVICE pointers; `stream` is a hipStream_t
+ *      (NULL = default stream).  Nothing here synchronises with the host unless stated. ------------------------ */
+typedef struct ugs_plan ugs_plan;
+/* Builds (or fetches from the plan cache) the plan of a batch through the same LRU as ugs_sample_batch_begin. */
+int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t num_cols, const int64_t *ptr,
+                          int64_t num_graphs, int k, ugs_plan **plan_out);
+/* Plan of one preprocessing handle (the handle API's graph). */
+int ugs_plan_create_handle(int64_t handle, ugs_plan **plan_out);
+int ugs_plan_release(ugs_plan *plan);
+/* num_graphs, total vertices, total CSR entries, bytes resident in HBM, walk-kernel tier chosen for k */
+int ugs_plan_info(const ugs_plan *plan, int k, int64_t *num_graphs, int64_t *num_vertices, int64_t *nnz,
+                  int64_t *device_bytes, int *tier);
+/* Walk phase for rows [row_begin, row_begin+row_count) of the G*m rows: writes d_nodes[row_count,k] and
+ * d_edge_ptr[row_count+1] (exclusive scan of the per-row edge-entry counts, starting at 0).
+ * If total_edges_host is not NULL the stream is synchronised and the total is returned there. */
+int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int seed,
+                  int64_t row_begin, int64_t row_count, void *stream, int64_t *d_nodes, int64_t *d_edge_ptr,
+                  int64_t *total_edges_host);
+/* Fill phase: writes d_edge_index[2, ld] (row stride ld >= total edges) and d_edge_src[...] for the same rows. */
+int ugs_plan_fill(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int64_t row_begin,
+                  int64_t row_count, void *stream, const int64_t *d_nodes, const int64_t *d_edge_ptr,
+                  int64_t *d_edge_index, int64_t ld, int64_t *d_edge_src);
+/* Name and per-launch statistics of the kernels the last ugs_plan_walk / ugs_plan_fill on this plan launched
+ * (grid, block, LDS bytes) -- used by bench.py to label its roofline line. */
+int ugs_plan_last_launch(const ugs_plan *plan, char *name_buf, int name_buf_len, int *grid, int *block,
+                         int *lds_bytes, int64_t *overflow_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UGS_MI355_H */

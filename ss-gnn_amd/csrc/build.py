@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Builds libugs_mi355.so (HIP kernels for gfx950 + host library behind the C ABI of include/ugs_mi355.h).
+In-tree build: the .so lands next to this file and travels with the repo snapshot (it is git-ignored)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "libugs_mi355.so")
+SRCS = [os.path.join(HERE, "ugs_kernels.hip"), os.path.join(HERE, "ugs_host.cpp")]
+DEPS = SRCS + [os.path.join(HERE, "ugs_device.h"), os.path.join(HERE, "..", "..", "include", "ugs_mi355.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def build(force=False, verbose=False):
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+        return OUT
+    objs = []
+    for src in SRCS:
+        obj = os.path.splitext(src)[0] + ".o"
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
+               "-x", "hip", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

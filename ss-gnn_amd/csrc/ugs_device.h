@@ -1,0 +1,106 @@
+// ugs_device.h -- structures shared by the host library (ugs_host.cpp) and the gfx950 kernels (ugs_kernels.hip).
+//
+// HBM layout of a *plan* (one PyG batch, or one graph of the handle API), all arrays resident in device memory:
+//
+//   graphs  UgsGraphDesc[G]          one 48-byte descriptor per graph
+//   rowptr  int64[sum(n_g + 1)]      ABSOLUTE offsets into adj/ecol (row r of graph g at rowptr[rbase_g + r])
+//   adj     int2[nnz]                (w, rank(w)) per CSR entry, CSR order = reference build_csr order
+//                                    (reference src/preproc.cpp:32-86).  rank(w) = index_of[w] is stored NEXT TO
+//                                    the neighbour so the suffix filter `index_of[w] >= root_vi`
+//                                    (reference src/sampler.cpp:62) costs no second (random) gather.
+//   ecol    int32[nnz]               value written to edge_src for this CSR entry (batch: column of the batch
+//                                    edge_index; handle API: column of the graph's edge_index)
+//   roots   UgsRootRec[sum(n_g)]     alias table row + both candidate root vertices in ONE 24-byte record, so the
+//                                    root draw (reference include/sampler.hpp:72-77 + src/sampler.cpp:165-173) is one gather
+//   viable  int2[...]                (vi, order[vi]) lists for relaxation levels 1/2 (reference src/sampler.cpp:121-150)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define UGS_KMAX 32          // largest supported k (per-walk vertex list lives in LDS / registers)
+
+struct UgsGraphDesc {
+    int64_t node_lo;      // added to local vertex ids in the nodes output (batch: ptr[g])
+    int64_t rbase;        // first rowptr entry of this graph
+    int64_t vbase;        // first roots[] entry of this graph
+    int64_t viable_base;  // first viable[] entry (levels 1, 2)
+    int32_t n;            // vertices
+    int32_t level;        // 0: alias-weighted roots; 1, 2: uniform over viable list; -1: degenerate (n <= 0 or n < k)
+    int32_t n_viable;
+    int32_t pad;
+};
+
+struct UgsRootRec {
+    double prob;          // alias-table acceptance probability of order position vi
+    int32_t alias;        // alias order position
+    int32_t v_self;       // order[vi]
+    int32_t v_alias;      // order[alias]
+    int32_t pad;
+};
+
+struct UgsPlanDev {
+    const UgsGraphDesc *graphs;
+    const int64_t *rowptr;
+    const int2 *adj;
+    const int32_t *ecol;
+    const UgsRootRec *roots;
+    const int2 *viable;
+    int64_t num_graphs;
+};
+
+struct UgsWalkArgs {
+    UgsPlanDev plan;
+    int32_t m;               // samples per graph
+    int32_t k;
+    int32_t mode;            // UGS_MODE_* / UGS_EDGE_* (0 local, 1 flat, 2 global)
+    int32_t pad;
+    int64_t extra_node_off;  // handle API "global": base_offset
+    uint64_t seed64;         // (uint64_t)(int64_t)seed
+    int64_t row_begin;       // first of the G*m rows produced by this call
+    int64_t row_count;
+    int64_t *nodes;          // [row_count, k]
+    uint32_t *counts;        // [row_count] edge entries per row
+    // overflow hand-off between tiers: rows whose candidate set outgrew the tier's LDS capacity
+    const int64_t *in_list;  // NULL: process rows 0..row_count-1; else process in_list[0..*in_count)
+    const uint32_t *in_count;
+    int64_t *ovf_list;       // rows (relative to row_begin) handed to the next tier
+    uint32_t *ovf_count;
+    // global-memory workspace of the last tier (per-group slices)
+    uint32_t *gws;
+    int64_t gws_words_per_group;
+    int64_t gws_groups;      // number of workspace slices = grid of the global tier
+    int32_t gcap;            // candidate capacity of the global tier
+    int32_t ghs;             // hash slots (power of two) of the global tier
+    int32_t gbcap;           // bucket-table entries of the global tier
+    int32_t gpcap;           // ordered-prefix capacity of the global tier
+};
+
+struct UgsFillArgs {
+    UgsPlanDev plan;
+    int32_t m, k, mode, pad;
+    int64_t extra_node_off;
+    int64_t row_begin, row_count;
+    const int64_t *nodes;
+    const int64_t *edge_ptr;   // [row_count + 1]
+    int64_t *edge_index;       // [2, ld]
+    int64_t ld;
+    int64_t *edge_src;
+};
+
+struct UgsLaunchInfo {
+    const char *name;
+    int grid, block, lds_bytes;
+};
+
+// tiers of the walk kernel: candidate-set capacity held in LDS per walk, lanes per walk
+enum { UGS_TIER_S = 0 /* cap 64, 8 lanes */, UGS_TIER_M = 1 /* cap 512, 64 lanes */, UGS_TIER_L = 2 /* cap 2048, 64 lanes */,
+       UGS_TIER_G = 3 /* global-memory workspace, 64 lanes */ };
+static const int UGS_TIER_CAP[3] = {64, 512, 2048};
+
+hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int device_cus, hipStream_t s, UgsLaunchInfo *info);
+hipError_t ugs_launch_scan(const uint32_t *counts, int64_t rows, int64_t *edge_ptr, int64_t *block_tmp, hipStream_t s);
+hipError_t ugs_launch_fill(const UgsFillArgs &a, int wide, int device_cus, hipStream_t s, UgsLaunchInfo *info);
+int64_t ugs_scan_tmp_words(int64_t rows);
+int64_t ugs_global_ws_words(int64_t gcap, int64_t gbcap, int64_t gpcap, int64_t ghs);
+uint32_t ugs_chain_at_least(int64_t c, int *index_out);
+uint32_t ugs_chain_value(int idx);

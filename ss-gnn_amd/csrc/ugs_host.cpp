@@ -1,0 +1,983 @@
+// ugs_host.cpp -- host side of libugs_mi355.so: graph preprocessing, handle registry, the batch LRU, device plans and
+// the C ABI of include/ugs_mi355.h.  Sampling itself runs only in the gfx950 kernels of ugs_kernels.hip; there is no
+// CPU sampling path in this library.
+//
+// Behavioural contract (what must come out bit-identical): the reference `ugs_sampler`
+// (AniruddhaMandal/SS-GNN src/samplers/ugs_sampler): preprocessing src/preproc.cpp:32-256 + include/sampler.hpp:39-69,
+// handle registry src/preproc.cpp:262-314, LRU + graph hash include/cache.hpp:15-109, batch wrapper
+// src/ugs_sampler_batch_extension.cpp:41-299.  The data structures here are flat arrays laid out for the GPU
+// (see ugs_device.h), not the reference's.
+#include "../../include/ugs_mi355.h"
+#include "ugs_device.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <list>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+struct ugs_plan;
+namespace { void plan_unref(ugs_plan *p); }
+
+namespace {
+
+thread_local std::string t_err;
+int fail(int code, const std::string &msg) { t_err = msg; return code; }
+int fail_hip(hipError_t e, const char *what) { return fail(UGS_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail_hip(e_, #expr); } while (0)
+
+bool debug_on() { static const bool on = [] { const char *e = std::getenv("UGS_DEBUG"); return e && std::string(e) == "1"; }(); return on; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// per-graph preprocessing result (host copy; the device plan is assembled from these)
+// ---------------------------------------------------------------------------------------------------------------
+struct Graph {
+    int64_t n = 0, nnz = 0;
+    int k_built = 0;
+    std::vector<int64_t> rowptr;      // n+1, 0-based
+    std::vector<int32_t> nbr, col;    // CSR neighbours and source column of each entry
+    std::vector<int32_t> order, rank; // order[vi] = vertex, rank[vertex] = vi
+    std::vector<int32_t> sdeg;        // suffix degree per order position
+    std::vector<double> weight;       // bucket weight per order position
+    std::vector<double> prob;         // alias table (only if Z > 0)
+    std::vector<int32_t> alias;
+    double Z = 0.0;
+    int nonzero = 0;
+    int level = 0;                    // relaxation level of the root draw
+    std::vector<int32_t> viable;      // order positions for levels 1, 2
+    int64_t max_deg = 0;
+    double sb_deg = 0.0;              // size-biased mean CSR degree (sum d^2 / sum d)
+    std::mutex plan_mu;
+    ugs_plan *plan = nullptr;         // device-resident copy for the handle API, built on first sample()
+    ~Graph() { if (plan) plan_unref(plan); }
+};
+
+// CSR of the symmetrised multigraph, entries in column order (both endpoints of column j, u's row first).
+void build_adjacency(Graph &G, const int64_t *src, const int64_t *dst, int64_t E) {
+    const int64_t n = G.n;
+    G.rowptr.assign((size_t)n + 1, 0);
+    for (int64_t j = 0; j < E; ++j) {
+        const int64_t u = src[j], v = dst[j];
+        if ((uint64_t)u >= (uint64_t)n || (uint64_t)v >= (uint64_t)n) continue;     // silently skipped columns
+        ++G.rowptr[(size_t)u + 1];
+        ++G.rowptr[(size_t)v + 1];
+    }
+    for (int64_t r = 0; r < n; ++r) G.rowptr[(size_t)r + 1] += G.rowptr[(size_t)r];
+    G.nnz = G.rowptr[(size_t)n];
+    G.nbr.resize((size_t)G.nnz);
+    G.col.resize((size_t)G.nnz);
+    std::vector<int64_t> wr(G.rowptr.begin(), G.rowptr.end() - 1);
+    for (int64_t j = 0; j < E; ++j) {
+        const int64_t u = src[j], v = dst[j];
+        if ((uint64_t)u >= (uint64_t)n || (uint64_t)v >= (uint64_t)n) continue;
+        int64_t a = wr[(size_t)u]++;
+        G.nbr[(size_t)a] = (int32_t)v; G.col[(size_t)a] = (int32_t)j;
+        int64_t b = wr[(size_t)v]++;
+        G.nbr[(size_t)b] = (int32_t)u; G.col[(size_t)b] = (int32_t)j;
+    }
+}
+
+// The reference's "remove the max-degree vertex, then reverse" ordering is the stable ascending sort by
+// (CSR degree, vertex id): every vertex is popped from the bucket of its ORIGINAL degree (later, lower-degree
+// duplicates are stale when reached), buckets drain high to low and back-to-front.  One counting sort.
+void order_by_degree(Graph &G) {
+    const int64_t n = G.n;
+    G.order.resize((size_t)n);
+    G.rank.resize((size_t)n);
+    int64_t maxd = 0;
+    double s1 = 0, s2 = 0;
+    for (int64_t v = 0; v < n; ++v) {
+        int64_t d = G.rowptr[(size_t)v + 1] - G.rowptr[(size_t)v];
+        maxd = std::max(maxd, d);
+        s1 += (double)d; s2 += (double)d * (double)d;
+    }
+    G.max_deg = maxd;
+    G.sb_deg = s1 > 0 ? s2 / s1 : 0.0;
+    std::vector<int64_t> start((size_t)maxd + 2, 0);
+    for (int64_t v = 0; v < n; ++v) ++start[(size_t)(G.rowptr[(size_t)v + 1] - G.rowptr[(size_t)v]) + 1];
+    for (int64_t d = 0; d <= maxd; ++d) start[(size_t)d + 1] += start[(size_t)d];
+    for (int64_t v = 0; v < n; ++v) {
+        int64_t d = G.rowptr[(size_t)v + 1] - G.rowptr[(size_t)v];
+        int64_t pos = start[(size_t)d]++;
+        G.order[(size_t)pos] = (int32_t)v;
+        G.rank[(size_t)v] = (int32_t)pos;
+    }
+}
+
+// Vose alias table, stacks filled in ascending index; order-sensitive IEEE arithmetic kept exactly
+// (p = w*n/sum; p[l] = (p[l] + p[s]) - 1.0).
+void build_alias(Graph &G) {
+    const int n = (int)G.n;
+    G.prob.assign((size_t)n, 0.0);
+    G.alias.assign((size_t)n, 0);
+    if (n == 0) return;
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) total += G.weight[(size_t)i];
+    const double denom = total > 0 ? total : 1.0;
+    std::vector<double> p((size_t)n);
+    std::vector<int32_t> lo, hi;
+    lo.reserve((size_t)n); hi.reserve((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        p[(size_t)i] = G.weight[(size_t)i] * n / denom;
+        (p[(size_t)i] < 1.0 ? lo : hi).push_back(i);
+    }
+    while (!lo.empty() && !hi.empty()) {
+        const int32_t s = lo.back(); lo.pop_back();
+        const int32_t l = hi.back();
+        G.prob[(size_t)s] = p[(size_t)s];
+        G.alias[(size_t)s] = l;
+        p[(size_t)l] = (p[(size_t)l] + p[(size_t)s]) - 1.0;
+        if (p[(size_t)l] < 1.0) { hi.pop_back(); lo.push_back(l); }
+    }
+    for (int32_t i : hi) G.prob[(size_t)i] = 1.0;
+    for (int32_t i : lo) G.prob[(size_t)i] = 1.0;
+}
+
+// suffix degrees, k-reachability of every root inside its suffix graph, bucket weights d^(k-1), Z, alias table.
+void weigh_roots(Graph &G, int k) {
+    const int n = (int)G.n;
+    G.sdeg.assign((size_t)n, 0);
+    for (int vi = 0; vi < n; ++vi) {
+        const int32_t v = G.order[(size_t)vi];
+        int32_t c = 0;
+        for (int64_t p = G.rowptr[(size_t)v]; p < G.rowptr[(size_t)v + 1]; ++p) c += G.rank[(size_t)G.nbr[(size_t)p]] >= vi;
+        G.sdeg[(size_t)vi] = c;
+    }
+    G.weight.assign((size_t)n, 0.0);
+    G.Z = 0.0;
+    G.nonzero = 0;
+    std::vector<int32_t> mark((size_t)n, -1), reached;
+    reached.reserve((size_t)std::max(k, 1) + 1);
+    for (int vi = 0; vi < n; ++vi) {
+        reached.clear();
+        reached.push_back(G.order[(size_t)vi]);
+        mark[(size_t)reached[0]] = vi;
+        for (size_t h = 0; h < reached.size() && (int)reached.size() < k; ++h) {
+            const int32_t u = reached[h];
+            for (int64_t p = G.rowptr[(size_t)u]; p < G.rowptr[(size_t)u + 1] && (int)reached.size() < k; ++p) {
+                const int32_t w = G.nbr[(size_t)p];
+                if (G.rank[(size_t)w] < vi || mark[(size_t)w] == vi) continue;
+                mark[(size_t)w] = vi;
+                reached.push_back(w);
+            }
+        }
+        if ((int)reached.size() >= k) {
+            const double d = (double)std::max<int32_t>(1, G.sdeg[(size_t)vi]);
+            double b = 1.0;
+            for (int t = 1; t < k; ++t) b *= d;
+            G.weight[(size_t)vi] = b;
+            G.Z += b;
+            if (b > 0.0) ++G.nonzero;
+        }
+    }
+    if (G.Z > 0.0) build_alias(G); else { G.prob.assign((size_t)n, 0.0); G.alias.assign((size_t)n, 0); }
+    // relaxation levels of the root draw
+    G.viable.clear();
+    if (G.nonzero > 0) G.level = 0;
+    else {
+        G.level = 1;
+        for (int vi = 0; vi < n; ++vi) if (G.sdeg[(size_t)vi] > 0) G.viable.push_back(vi);
+        if (G.viable.empty()) { G.level = 2; for (int vi = 0; vi < n; ++vi) G.viable.push_back(vi); }
+    }
+    if (debug_on()) std::fprintf(stderr, "[UGS PREPROC] n=%d k=%d Z=%.2e viable=%d/%d\n", n, k, G.Z, G.nonzero, n);
+}
+
+int make_graph(const int64_t *src, const int64_t *dst, int64_t E, int64_t n, int k, std::shared_ptr<Graph> &out) {
+    if (n < 0) return fail(UGS_E_BAD_ARG, "num_nodes must be >= 0");
+    if (n >= (int64_t)INT32_MAX || E >= (int64_t)INT32_MAX) return fail(UGS_E_UNSUPPORTED, "graph too large: num_nodes and columns must be < 2^31 - 1");
+    auto G = std::make_shared<Graph>();
+    G->n = n;
+    G->k_built = k;
+    build_adjacency(*G, src, dst, E);
+    if (G->nnz >= (int64_t)INT32_MAX) return fail(UGS_E_UNSUPPORTED, "graph too large: CSR entries must be < 2^31 - 1");
+    order_by_degree(*G);
+    weigh_roots(*G, k);
+    out = std::move(G);
+    return UGS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// handle registry (monotonically increasing int64 handles from 1)
+// ---------------------------------------------------------------------------------------------------------------
+std::mutex g_reg_mu;
+std::unordered_map<int64_t, std::shared_ptr<Graph>> g_reg;
+int64_t g_next_handle = 1;
+
+std::shared_ptr<Graph> lookup(int64_t h) {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = g_reg.find(h);
+    return it == g_reg.end() ? nullptr : it->second;
+}
+int64_t enroll(std::shared_ptr<Graph> g) {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    int64_t h = g_next_handle++;
+    g_reg[h] = std::move(g);
+    return h;
+}
+void drop(int64_t h) { std::lock_guard<std::mutex> lk(g_reg_mu); g_reg.erase(h); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// batch LRU: graph hash -> handle.  Capacity from UGS_CACHE_SIZE (default 1000); capacity 0 never evicts.
+// The key deliberately matches the reference's (FNV-1a over n, #cols and (strided) renumbered columns, NOT k), so
+// that the same call history produces the same reuse -- including reuse of weights built for another k.
+// ---------------------------------------------------------------------------------------------------------------
+struct Lru {
+    size_t capacity = 1000;
+    std::list<std::pair<uint64_t, int64_t>> items;     // front = most recent
+    std::unordered_map<uint64_t, std::list<std::pair<uint64_t, int64_t>>::iterator> index;
+    int64_t hits = 0, misses = 0;
+    bool get(uint64_t key, int64_t &val) {
+        auto it = index.find(key);
+        if (it == index.end()) return false;
+        items.splice(items.begin(), items, it->second);
+        val = it->second->second;
+        return true;
+    }
+    bool put(uint64_t key, int64_t val, int64_t &evicted) {   // true if something was evicted
+        auto it = index.find(key);
+        if (it != index.end()) { it->second->second = val; items.splice(items.begin(), items, it->second); return false; }
+        bool ev = false;
+        if (capacity > 0 && items.size() >= capacity) {
+            evicted = items.back().second;
+            index.erase(items.back().first);
+            items.pop_back();
+            ev = true;
+        }
+        items.emplace_front(key, val);
+        index[key] = items.begin();
+        return ev;
+    }
+};
+std::mutex g_lru_mu;
+Lru *g_lru = nullptr;
+Lru &lru() {   // call with g_lru_mu held
+    if (!g_lru) {
+        g_lru = new Lru();
+        if (const char *e = std::getenv("UGS_CACHE_SIZE")) g_lru->capacity = (size_t)std::atoi(e);
+        if (debug_on()) std::fprintf(stderr, "[UGS INFO] Preprocessing cache initialized: size=%zu (set UGS_CACHE_SIZE to change)\n", g_lru->capacity);
+    }
+    return *g_lru;
+}
+
+uint64_t graph_key(const int64_t *u, const int64_t *v, int64_t cols, int64_t n) {
+    const uint64_t prime = 1099511628211ull;
+    uint64_t h = 14695981039346656037ull;
+    h = (h ^ (uint64_t)n) * prime;
+    h = (h ^ (uint64_t)cols) * prime;
+    const int64_t step = cols > 1000 ? cols / 500 : 1;
+    for (int64_t j = 0; j < cols; j += step) { h = (h ^ (uint64_t)u[j]) * prime; h = (h ^ (uint64_t)v[j]) * prime; }
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------------------------
+struct DeviceCtx { int id = -1; int cus = 256; hipStream_t stream = nullptr; };
+std::mutex g_dev_mu;
+std::map<int, DeviceCtx> g_devs;
+thread_local int t_device = -1;
+
+int device_ctx(DeviceCtx &out) {
+    int dev = t_device;
+    if (dev < 0) {
+        int cnt = 0;
+        hipError_t e = hipGetDeviceCount(&cnt);
+        if (e != hipSuccess || cnt <= 0) return fail(UGS_E_NO_DEVICE, "no usable HIP device: this sampler has no CPU path (hipGetDeviceCount: " + std::string(hipGetErrorString(e)) + ")");
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    HIP_TRY(hipSetDevice(dev));
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    auto it = g_devs.find(dev);
+    if (it == g_devs.end()) {
+        DeviceCtx c;
+        c.id = dev;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        it = g_devs.emplace(dev, c).first;
+    }
+    out = it->second;
+    return UGS_OK;
+}
+
+// grow-only device scratch pool (per process): avoids hipMalloc/hipFree on every call
+struct PoolBuf { void *p = nullptr; size_t bytes = 0; int dev = -1; };
+std::mutex g_pool_mu;
+std::vector<PoolBuf> g_pool_free;
+int pool_get(size_t bytes, int dev, PoolBuf &out) {
+    if (bytes < 256) bytes = 256;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        int best = -1;
+        for (int i = 0; i < (int)g_pool_free.size(); ++i)
+            if (g_pool_free[(size_t)i].dev == dev && g_pool_free[(size_t)i].bytes >= bytes &&
+                (best < 0 || g_pool_free[(size_t)i].bytes < g_pool_free[(size_t)best].bytes)) best = i;
+        if (best >= 0 && g_pool_free[(size_t)best].bytes <= 4 * bytes + (1u << 20)) {
+            out = g_pool_free[(size_t)best];
+            g_pool_free.erase(g_pool_free.begin() + best);
+            return UGS_OK;
+        }
+    }
+    size_t rounded = (bytes + (bytes >> 2) + 4095) & ~(size_t)4095;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, rounded);
+    if (e != hipSuccess) {   // drop the pool and retry once
+        std::vector<PoolBuf> victims;
+        { std::lock_guard<std::mutex> lk(g_pool_mu); victims.swap(g_pool_free); }
+        for (auto &b : victims) (void)hipFree(b.p);
+        e = hipMalloc(&p, rounded);
+        if (e != hipSuccess) return fail_hip(e, "hipMalloc");
+    }
+    out.p = p; out.bytes = rounded; out.dev = dev;
+    return UGS_OK;
+}
+void pool_put(PoolBuf &b) {
+    if (!b.p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_free.push_back(b);
+    b = PoolBuf();
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// plans
+// ---------------------------------------------------------------------------------------------------------------
+struct TierChoice { int first = UGS_TIER_S; bool second_L = false; bool third_G = false; int64_t bound = 0; };
+
+struct ugs_plan {
+    int device = -1, cus = 256;
+    int64_t G = 0, nverts = 0, nnz = 0;
+    void *blob = nullptr;                 // one device allocation holding every array of the plan
+    size_t blob_bytes = 0;
+    UgsPlanDev dev{};
+    // per-graph statistics used to pick the walk tier for a given k
+    std::vector<int64_t> g_n, g_maxdeg;
+    std::vector<double> g_sbdeg;
+    std::vector<int> g_level;
+    std::mutex mu;
+    std::map<int, TierChoice> tiers;
+    std::atomic<int> refs{1};
+    uint64_t cache_key = 0;
+    bool cached = false;
+    // lazily grown scratch owned by the plan (serialised by `mu` per call)
+    PoolBuf counts, ovf1, ovf2, ovfcnt, scantmp, gws;
+    int64_t gws_groups = 0, gws_words = 0;
+    int gcap = 0, ghs = 0, gbcap = 0, gpcap = 0;
+    UgsLaunchInfo last_walk{nullptr, 0, 0, 0};
+    int64_t last_overflow = 0;
+    bool handle_api = false;
+};
+
+namespace {
+
+struct PlanPiece {                 // one graph of a plan
+    std::shared_ptr<Graph> g;      // null for degenerate graphs
+    int64_t lo = 0;
+    const int64_t *colmap = nullptr;   // batch column of each of the graph's columns (null: identity)
+};
+
+size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+int assemble_plan(const std::vector<PlanPiece> &pieces, const DeviceCtx &dc, ugs_plan *plan) {
+    const int64_t G = (int64_t)pieces.size();
+    int64_t nv = 0, nnz = 0, nrows = 0, nviable = 0;
+    for (auto &pc : pieces) if (pc.g) { nv += pc.g->n; nnz += pc.g->nnz; nrows += pc.g->n + 1; if (pc.g->level > 0) nviable += (int64_t)pc.g->viable.size(); }
+    if (nnz >= (int64_t)INT32_MAX) return fail(UGS_E_UNSUPPORTED, "plan too large: total CSR entries must be < 2^31 - 1");
+    size_t off_desc = 0;
+    size_t off_row = align_up(off_desc + (size_t)std::max<int64_t>(G, 1) * sizeof(UgsGraphDesc));
+    size_t off_adj = align_up(off_row + (size_t)std::max<int64_t>(nrows, 1) * sizeof(int64_t));
+    size_t off_col = align_up(off_adj + (size_t)std::max<int64_t>(nnz, 1) * sizeof(int2));
+    size_t off_root = align_up(off_col + (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t));
+    size_t off_via = align_up(off_root + (size_t)std::max<int64_t>(nv, 1) * sizeof(UgsRootRec));
+    size_t total = align_up(off_via + (size_t)std::max<int64_t>(nviable, 1) * sizeof(int2));
+    std::vector<char> host(total, 0);
+    auto *desc = reinterpret_cast<UgsGraphDesc *>(host.data() + off_desc);
+    auto *rowp = reinterpret_cast<int64_t *>(host.data() + off_row);
+    auto *adj = reinterpret_cast<int2 *>(host.data() + off_adj);
+    auto *ecol = reinterpret_cast<int32_t *>(host.data() + off_col);
+    auto *roots = reinterpret_cast<UgsRootRec *>(host.data() + off_root);
+    auto *via = reinterpret_cast<int2 *>(host.data() + off_via);
+    int64_t rb = 0, vb = 0, ab = 0, vib = 0;
+    plan->g_n.resize((size_t)G); plan->g_maxdeg.resize((size_t)G); plan->g_sbdeg.resize((size_t)G); plan->g_level.resize((size_t)G);
+    for (int64_t gi = 0; gi < G; ++gi) {
+        const PlanPiece &pc = pieces[(size_t)gi];
+        UgsGraphDesc &d = desc[gi];
+        d.node_lo = pc.lo; d.rbase = rb; d.vbase = vb; d.viable_base = vib; d.pad = 0;
+        if (!pc.g) { d.n = 0; d.level = -1; d.n_viable = 0; plan->g_n[(size_t)gi] = 0; plan->g_maxdeg[(size_t)gi] = 0; plan->g_sbdeg[(size_t)gi] = 0; plan->g_level[(size_t)gi] = -1; continue; }
+        const Graph &g = *pc.g;
+        d.n = (int32_t)g.n; d.level = g.level; d.n_viable = (int32_t)g.viable.size();
+        plan->g_n[(size_t)gi] = g.n; plan->g_maxdeg[(size_t)gi] = g.max_deg; plan->g_sbdeg[(size_t)gi] = g.sb_deg; plan->g_level[(size_t)gi] = g.level;
+        for (int64_t r = 0; r <= g.n; ++r) rowp[rb + r] = ab + g.rowptr[(size_t)r];
+        for (int64_t p = 0; p < g.nnz; ++p) {
+            const int32_t w = g.nbr[(size_t)p];
+            adj[ab + p] = make_int2(w, g.rank[(size_t)w]);
+            const int32_t c = g.col[(size_t)p];
+            ecol[ab + p] = pc.colmap ? (int32_t)pc.colmap[c] : c;
+        }
+        if (g.level == 0)
+            for (int64_t vi = 0; vi < g.n; ++vi) {
+                UgsRootRec &r = roots[vb + vi];
+                r.prob = g.prob[(size_t)vi]; r.alias = g.alias[(size_t)vi];
+                r.v_self = g.order[(size_t)vi]; r.v_alias = g.order[(size_t)g.alias[(size_t)vi]]; r.pad = 0;
+            }
+        else
+            for (size_t t = 0; t < g.viable.size(); ++t) via[vib + (int64_t)t] = make_int2(g.viable[t], g.order[(size_t)g.viable[t]]);
+        rb += g.n + 1; vb += g.n; ab += g.nnz; if (g.level > 0) vib += (int64_t)g.viable.size();
+    }
+    void *dptr = nullptr;
+    HIP_TRY(hipMalloc(&dptr, total));
+    hipError_t e = hipMemcpy(dptr, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(dptr); return fail_hip(e, "hipMemcpy(plan)"); }
+    plan->device = dc.id; plan->cus = dc.cus;
+    plan->G = G; plan->nverts = nv; plan->nnz = nnz;
+    plan->blob = dptr; plan->blob_bytes = total;
+    char *base = static_cast<char *>(dptr);
+    plan->dev.graphs = reinterpret_cast<const UgsGraphDesc *>(base + off_desc);
+    plan->dev.rowptr = reinterpret_cast<const int64_t *>(base + off_row);
+    plan->dev.adj = reinterpret_cast<const int2 *>(base + off_adj);
+    plan->dev.ecol = reinterpret_cast<const int32_t *>(base + off_col);
+    plan->dev.roots = reinterpret_cast<const UgsRootRec *>(base + off_root);
+    plan->dev.viable = reinterpret_cast<const int2 *>(base + off_via);
+    plan->dev.num_graphs = G;
+    return UGS_OK;
+}
+
+void destroy_plan(ugs_plan *p) {
+    if (!p) return;
+    if (p->blob) (void)hipFree(p->blob);
+    pool_put(p->counts); pool_put(p->ovf1); pool_put(p->ovf2); pool_put(p->ovfcnt); pool_put(p->scantmp);
+    if (p->gws.p) { (void)hipFree(p->gws.p); p->gws = PoolBuf(); }
+    delete p;
+}
+}  // namespace
+namespace { void plan_unref(ugs_plan *p) { if (p && p->refs.fetch_sub(1) == 1) destroy_plan(p); } }
+namespace {
+
+// plan cache of batches (small LRU; a hit skips assembly + upload)
+std::mutex g_pc_mu;
+std::list<ugs_plan *> g_plan_cache;     // front = most recent
+size_t g_plan_cache_cap = 64;
+size_t g_plan_cache_bytes_cap = (size_t)8 << 30;
+
+ugs_plan *plan_cache_get(uint64_t key, int dev) {
+    std::lock_guard<std::mutex> lk(g_pc_mu);
+    for (auto it = g_plan_cache.begin(); it != g_plan_cache.end(); ++it)
+        if ((*it)->cache_key == key && (*it)->device == dev) {
+            ugs_plan *p = *it;
+            g_plan_cache.splice(g_plan_cache.begin(), g_plan_cache, it);
+            p->refs.fetch_add(1);
+            return p;
+        }
+    return nullptr;
+}
+void plan_cache_put(ugs_plan *p) {
+    std::vector<ugs_plan *> victims;
+    {
+        std::lock_guard<std::mutex> lk(g_pc_mu);
+        p->refs.fetch_add(1);
+        p->cached = true;
+        g_plan_cache.push_front(p);
+        size_t bytes = 0;
+        for (auto *q : g_plan_cache) bytes += q->blob_bytes;
+        while (g_plan_cache.size() > g_plan_cache_cap || (bytes > g_plan_cache_bytes_cap && g_plan_cache.size() > 1)) {
+            ugs_plan *v = g_plan_cache.back();
+            g_plan_cache.pop_back();
+            bytes -= v->blob_bytes;
+            victims.push_back(v);
+        }
+    }
+    for (auto *v : victims) plan_unref(v);
+}
+void plan_cache_clear() {
+    std::vector<ugs_plan *> victims;
+    { std::lock_guard<std::mutex> lk(g_pc_mu); victims.assign(g_plan_cache.begin(), g_plan_cache.end()); g_plan_cache.clear(); }
+    for (auto *v : victims) plan_unref(v);
+}
+
+// pick the walk tier(s) for k: the candidate set of a walk holds at most min(n-1, (k-1)*max degree) vertices
+TierChoice choose_tier(ugs_plan *p, int k) {
+    std::lock_guard<std::mutex> lk(p->mu);
+    auto it = p->tiers.find(k);
+    if (it != p->tiers.end()) return it->second;
+    int64_t bound = 0;
+    double est = 0;
+    for (size_t gi = 0; gi < p->g_n.size(); ++gi) {
+        if (p->g_level[gi] < 0) continue;
+        const int64_t b = std::max<int64_t>(0, std::min<int64_t>(p->g_n[gi] - 1, (int64_t)(k - 1) * p->g_maxdeg[gi]));
+        bound = std::max(bound, b);
+        est = std::max(est, std::min<double>((double)b, 1.3 * (k - 1) * p->g_sbdeg[gi] + 16.0));
+    }
+    TierChoice t;
+    t.bound = bound;
+    if (est <= UGS_TIER_CAP[0] || bound <= UGS_TIER_CAP[0]) t.first = UGS_TIER_S;
+    else if (est <= UGS_TIER_CAP[1] || bound <= UGS_TIER_CAP[1]) t.first = UGS_TIER_M;
+    else t.first = UGS_TIER_L;
+    if (const char *e = std::getenv("UGS_FORCE_TIER")) { int f = std::atoi(e); if (f >= 0 && f <= 2) t.first = f; }
+    t.second_L = t.first < UGS_TIER_L && bound > UGS_TIER_CAP[t.first];
+    t.third_G = bound > UGS_TIER_CAP[2];
+    p->tiers[k] = t;
+    return t;
+}
+
+int ensure(PoolBuf &b, size_t bytes, int dev) {
+    if (b.p && b.bytes >= bytes) return UGS_OK;
+    pool_put(b);
+    return pool_get(bytes, dev, b);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *ugs_last_error(void) { return t_err.c_str(); }
+const char *ugs_version(void) { return "ugs-mi355 0.1 (gfx950)"; }
+
+int ugs_device_count(int *count) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess || c <= 0) { if (count) *count = 0; return fail(UGS_E_NO_DEVICE, std::string("no usable HIP device: ") + hipGetErrorString(e)); }
+    if (count) *count = c;
+    return UGS_OK;
+}
+
+int ugs_set_device(int device) {
+    int c = 0;
+    if (int rc = ugs_device_count(&c)) return rc;
+    if (device < 0 || device >= c) return fail(UGS_E_BAD_ARG, "device index out of range");
+    t_device = device;
+    HIP_TRY(hipSetDevice(device));
+    return UGS_OK;
+}
+
+int ugs_create_preproc(const int64_t *edge_index, int64_t row_stride, int64_t num_cols, int64_t num_nodes, int k, int64_t *handle_out) {
+    if (!handle_out || (num_cols > 0 && !edge_index) || num_cols < 0) return fail(UGS_E_BAD_ARG, "bad arguments to create_preproc");
+    std::shared_ptr<Graph> g;
+    if (int rc = make_graph(edge_index, edge_index + row_stride, num_cols, num_nodes, k, g)) return rc;
+    *handle_out = enroll(std::move(g));
+    return UGS_OK;
+}
+
+int ugs_destroy_preproc(int64_t handle) { drop(handle); return UGS_OK; }
+
+int ugs_has_graphlets(int64_t handle, int *out) {
+    auto g = lookup(handle);
+    if (out) *out = (g && g->Z > 0.0) ? 1 : 0;
+    return UGS_OK;
+}
+
+int ugs_get_preproc_info(int64_t handle, int *found, int64_t *num_nodes, int64_t *num_edges_stored, double *Z, int *bucket_count_nonzero) {
+    auto g = lookup(handle);
+    if (found) *found = g ? 1 : 0;
+    if (!g) return UGS_OK;
+    if (num_nodes) *num_nodes = g->n;
+    if (num_edges_stored) *num_edges_stored = g->nnz;
+    if (Z) *Z = g->Z;
+    if (bucket_count_nonzero) *bucket_count_nonzero = g->nonzero;
+    return UGS_OK;
+}
+
+int ugs_preproc_dump(int64_t handle, int64_t *indptr, int32_t *indices, int32_t *edge_col, int32_t *order, int32_t *index_of,
+                     int32_t *suffix_deg, double *bucket_b, double *prob, int32_t *alias) {
+    auto g = lookup(handle);
+    if (!g) return fail(UGS_E_INVALID_HANDLE, "Invalid preproc handle");
+    const size_t n = (size_t)g->n, nnz = (size_t)g->nnz;
+    if (indptr) std::memcpy(indptr, g->rowptr.data(), (n + 1) * sizeof(int64_t));
+    if (indices && nnz) std::memcpy(indices, g->nbr.data(), nnz * sizeof(int32_t));
+    if (edge_col && nnz) std::memcpy(edge_col, g->col.data(), nnz * sizeof(int32_t));
+    if (order && n) std::memcpy(order, g->order.data(), n * sizeof(int32_t));
+    if (index_of && n) std::memcpy(index_of, g->rank.data(), n * sizeof(int32_t));
+    if (suffix_deg && n) std::memcpy(suffix_deg, g->sdeg.data(), n * sizeof(int32_t));
+    if (bucket_b && n) std::memcpy(bucket_b, g->weight.data(), n * sizeof(double));
+    if (prob && n) std::memcpy(prob, g->prob.data(), n * sizeof(double));
+    if (alias && n) std::memcpy(alias, g->alias.data(), n * sizeof(int32_t));
+    return UGS_OK;
+}
+
+int ugs_cache_clear(void) {
+    {
+        std::lock_guard<std::mutex> lk(g_lru_mu);
+        Lru &c = lru();
+        for (auto &kv : c.items) drop(kv.second);
+        c.items.clear(); c.index.clear(); c.hits = c.misses = 0;
+    }
+    plan_cache_clear();
+    return UGS_OK;
+}
+
+int ugs_cache_stats(int64_t *size, int64_t *hits, int64_t *misses) {
+    std::lock_guard<std::mutex> lk(g_lru_mu);
+    Lru &c = lru();
+    if (size) *size = (int64_t)c.items.size();
+    if (hits) *hits = c.hits;
+    if (misses) *misses = c.misses;
+    return UGS_OK;
+}
+
+// ---- plans ------------------------------------------------------------------------------------------------------
+int ugs_plan_create_handle(int64_t handle, ugs_plan **plan_out) {
+    if (!plan_out) return fail(UGS_E_BAD_ARG, "plan_out is null");
+    auto g = lookup(handle);
+    if (!g) return fail(UGS_E_INVALID_HANDLE, "Invalid preproc handle");
+    DeviceCtx dc;
+    if (int rc = device_ctx(dc)) return rc;
+    std::lock_guard<std::mutex> lk(g->plan_mu);
+    if (g->plan && g->plan->device == dc.id) { g->plan->refs.fetch_add(1); *plan_out = g->plan; return UGS_OK; }
+    auto *p = new ugs_plan();
+    p->handle_api = true;
+    std::vector<PlanPiece> pieces(1);
+    pieces[0].g = g;                       // note: the plan keeps the Graph alive only through its arrays on the device
+    if (int rc = assemble_plan(pieces, dc, p)) { delete p; return rc; }
+    if (!g->plan) { g->plan = p; p->refs.fetch_add(1); }
+    *plan_out = p;
+    return UGS_OK;
+}
+
+int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t num_cols, const int64_t *ptr, int64_t num_graphs,
+                          int k, ugs_plan **plan_out) {
+    if (!plan_out || !ptr || num_graphs < 0 || num_cols < 0 || (num_cols > 0 && !edge_index)) return fail(UGS_E_BAD_ARG, "bad arguments to sample_batch");
+    if (num_cols >= (int64_t)INT32_MAX) return fail(UGS_E_UNSUPPORTED, "batch too large: columns must be < 2^31 - 1");
+    DeviceCtx dc;
+    if (int rc = device_ctx(dc)) return rc;
+    const int64_t G = num_graphs, E = num_cols;
+    const int64_t *src = edge_index, *dst = edge_index + row_stride;
+    // --- assign every column to the graph whose node range holds both endpoints, keeping column order --------------
+    bool monotone = true;
+    for (int64_t g = 0; g < G; ++g) if (ptr[g + 1] < ptr[g]) { monotone = false; break; }
+    std::vector<int64_t> cstart((size_t)G + 1, 0), cols_of;   // per-graph column lists, concatenated
+    if (monotone) {
+        std::vector<int32_t> owner((size_t)E, -1);
+        for (int64_t j = 0; j < E; ++j) {
+            const int64_t u = src[j], v = dst[j];
+            if (G == 0 || u < ptr[0] || u >= ptr[G]) continue;
+            int64_t g = (std::upper_bound(ptr, ptr + G + 1, u) - ptr) - 1;    // last g with ptr[g] <= u
+            while (g + 1 <= G - 1 && ptr[g + 1] <= u) ++g;
+            if (g < 0 || g >= G || !(u >= ptr[g] && u < ptr[g + 1])) continue;
+            if (v >= ptr[g] && v < ptr[g + 1]) { owner[(size_t)j] = (int32_t)g; ++cstart[(size_t)g + 1]; }
+        }
+        for (int64_t g = 0; g < G; ++g) cstart[(size_t)g + 1] += cstart[(size_t)g];
+        cols_of.resize((size_t)cstart[(size_t)G]);
+        std::vector<int64_t> wr(cstart.begin(), cstart.end() - 1);
+        for (int64_t j = 0; j < E; ++j) if (owner[(size_t)j] >= 0) cols_of[(size_t)wr[(size_t)owner[(size_t)j]]++] = j;
+    } else {   // arbitrary ptr: every graph scans every column, like the reference
+        for (int64_t g = 0; g < G; ++g) {
+            const int64_t lo = ptr[g], hi = ptr[g + 1];
+            for (int64_t j = 0; j < E; ++j) if (src[j] >= lo && src[j] < hi && dst[j] >= lo && dst[j] < hi) cols_of.push_back(j);
+            cstart[(size_t)g + 1] = (int64_t)cols_of.size();
+        }
+    }
+    // --- per graph: renumber, hash, LRU lookup / preprocessing ------------------------------------------------------
+    std::vector<PlanPiece> pieces((size_t)G);
+    std::vector<int64_t> ru, rv, evicted;
+    uint64_t pkey = 14695981039346656037ull;
+    const uint64_t prime = 1099511628211ull;
+    auto mix = [&](uint64_t x) { pkey = (pkey ^ x) * prime; };
+    mix((uint64_t)G);
+    int64_t hits = 0, misses = 0;
+    for (int64_t g = 0; g < G; ++g) {
+        PlanPiece &pc = pieces[(size_t)g];
+        const int64_t lo = ptr[g], hi = ptr[g + 1], n = hi - lo;
+        pc.lo = lo;
+        mix((uint64_t)lo);
+        if (n <= 0 || n < k) { mix(0x9e3779b97f4a7c15ull); continue; }        // degenerate: m rows of -1
+        const int64_t c0 = cstart[(size_t)g], cn = cstart[(size_t)g + 1] - c0;
+        ru.resize((size_t)cn); rv.resize((size_t)cn);
+        for (int64_t t = 0; t < cn; ++t) { const int64_t j = cols_of[(size_t)(c0 + t)]; ru[(size_t)t] = src[j] - lo; rv[(size_t)t] = dst[j] - lo; }
+        const uint64_t key = graph_key(ru.data(), rv.data(), cn, n);
+        int64_t handle = 0;
+        bool hit;
+        {
+            std::lock_guard<std::mutex> lk(g_lru_mu);
+            hit = lru().get(key, handle);
+            if (hit) ++lru().hits; else ++lru().misses;
+        }
+        std::shared_ptr<Graph> gr = hit ? lookup(handle) : nullptr;
+        if (!gr) {
+            if (int rc = make_graph(ru.data(), rv.data(), cn, n, k, gr)) return rc;
+            handle = enroll(gr);
+            int64_t ev = 0;
+            std::lock_guard<std::mutex> lk(g_lru_mu);
+            if (lru().put(key, handle, ev)) evicted.push_back(ev);
+            ++misses;
+        } else ++hits;
+        pc.g = gr;
+        pc.colmap = cols_of.data() + c0;
+        mix((uint64_t)handle); mix((uint64_t)cn);
+        for (int64_t t = 0; t < cn; ++t) mix((uint64_t)cols_of[(size_t)(c0 + t)]);
+    }
+    for (int64_t h : evicted) drop(h);          // only evicted handles are destroyed; cached ones live on
+    if (debug_on()) {
+        std::lock_guard<std::mutex> lk(g_lru_mu);
+        std::fprintf(stderr, "[UGS CACHE] hits=%lld misses=%lld cache_size=%zu\n", (long long)hits, (long long)misses, lru().items.size());
+    }
+    if (ugs_plan *cached = plan_cache_get(pkey, dc.id)) { *plan_out = cached; return UGS_OK; }
+    auto *p = new ugs_plan();
+    p->cache_key = pkey;
+    if (int rc = assemble_plan(pieces, dc, p)) { delete p; return rc; }
+    plan_cache_put(p);
+    *plan_out = p;
+    return UGS_OK;
+}
+
+int ugs_plan_release(ugs_plan *plan) { plan_unref(plan); return UGS_OK; }
+
+int ugs_plan_info(const ugs_plan *plan, int k, int64_t *num_graphs, int64_t *num_vertices, int64_t *nnz, int64_t *device_bytes, int *tier) {
+    if (!plan) return fail(UGS_E_BAD_ARG, "plan is null");
+    if (num_graphs) *num_graphs = plan->G;
+    if (num_vertices) *num_vertices = plan->nverts;
+    if (nnz) *nnz = plan->nnz;
+    if (device_bytes) *device_bytes = (int64_t)plan->blob_bytes;
+    if (tier) *tier = choose_tier(const_cast<ugs_plan *>(plan), k).first;
+    return UGS_OK;
+}
+
+int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int seed, int64_t row_begin,
+                  int64_t row_count, void *stream, int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *total_edges_host) {
+    if (!plan) return fail(UGS_E_BAD_ARG, "plan is null");
+    if (k < 1) return fail(UGS_E_BAD_ARG, "k must be >= 1");
+    if (k > UGS_KMAX) return fail(UGS_E_UNSUPPORTED, "k > 32 is not supported by the HIP sampler");
+    if (mode < 0 || mode > 2) return fail(UGS_E_BAD_MODE, "mode must be one of: 'sample', 'graph', 'global'");
+    if (m_per_graph < 0 || row_begin < 0 || row_count < 0 || row_begin + row_count > plan->G * (int64_t)m_per_graph)
+        return fail(UGS_E_BAD_ARG, "row range outside [0, num_graphs * m_per_graph)");
+    if (row_count > 0 && (!d_nodes || !d_edge_ptr)) return fail(UGS_E_BAD_ARG, "null output pointer");
+    HIP_TRY(hipSetDevice(plan->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (row_count == 0) {
+        if (d_edge_ptr) HIP_TRY(hipMemsetAsync(d_edge_ptr, 0, sizeof(int64_t), s));
+        if (total_edges_host) { HIP_TRY(hipStreamSynchronize(s)); *total_edges_host = 0; }
+        return UGS_OK;
+    }
+    const TierChoice tc = choose_tier(plan, k);
+    std::lock_guard<std::mutex> lk(plan->mu);
+    if (int rc = ensure(plan->counts, (size_t)row_count * sizeof(uint32_t), plan->device)) return rc;
+    if (int rc = ensure(plan->scantmp, (size_t)ugs_scan_tmp_words(row_count) * sizeof(int64_t), plan->device)) return rc;
+    if (int rc = ensure(plan->ovfcnt, 4 * sizeof(uint32_t), plan->device)) return rc;
+    const bool may_overflow = tc.second_L || tc.third_G;
+    if (may_overflow) {
+        if (int rc = ensure(plan->ovf1, (size_t)row_count * sizeof(int64_t), plan->device)) return rc;
+        if (int rc = ensure(plan->ovf2, (size_t)row_count * sizeof(int64_t), plan->device)) return rc;
+    }
+    HIP_TRY(hipMemsetAsync(plan->ovfcnt.p, 0, 4 * sizeof(uint32_t), s));
+    uint32_t *cnt = static_cast<uint32_t *>(plan->ovfcnt.p);
+    UgsWalkArgs a{};
+    a.plan = plan->dev;
+    a.m = m_per_graph; a.k = k; a.mode = mode;
+    a.extra_node_off = extra_node_offset;
+    a.seed64 = (uint64_t)(int64_t)seed;
+    a.row_begin = row_begin; a.row_count = row_count;
+    a.nodes = d_nodes;
+    a.counts = static_cast<uint32_t *>(plan->counts.p);
+    a.in_list = nullptr; a.in_count = nullptr;
+    a.ovf_list = static_cast<int64_t *>(plan->ovf1.p);
+    a.ovf_count = cnt + 0;
+    HIP_TRY(ugs_launch_walk(a, tc.first, plan->cus, s, &plan->last_walk));
+    int last = 0;   // index of the counter holding rows that nobody processed
+    if (tc.second_L) {
+        a.in_list = static_cast<const int64_t *>(plan->ovf1.p); a.in_count = cnt + 0;
+        a.ovf_list = static_cast<int64_t *>(plan->ovf2.p); a.ovf_count = cnt + 1;
+        HIP_TRY(ugs_launch_walk(a, UGS_TIER_L, plan->cus, s, nullptr));
+        last = 1;
+    }
+    if (tc.third_G) {
+        if (!plan->gws.p) {
+            int idx = 0;
+            const int64_t gcap = std::max<int64_t>(tc.bound, 1);
+            const uint32_t gb = ugs_chain_at_least(gcap, &idx);
+            if (!gb) return fail(UGS_E_UNSUPPORTED, "candidate-set bound too large");
+            const int64_t prev = idx > 0 ? (int64_t)ugs_chain_value(idx - 1) : 1;   // longest ordered prefix ever materialised
+            int64_t hs = 128;
+            while (hs < 2 * (gcap + 65 + 1)) hs <<= 1;
+            const int64_t words = ugs_global_ws_words(gcap, gb, prev, hs);
+            int64_t groups = std::min<int64_t>(256, std::max<int64_t>(1, ((int64_t)4 << 30) / (words * 4)));
+            if (words * 4 > ((int64_t)16 << 30)) return fail(UGS_E_UNSUPPORTED, "candidate-set bound too large for the global-memory workspace");
+            void *w = nullptr;
+            HIP_TRY(hipMalloc(&w, (size_t)(words * groups) * sizeof(uint32_t)));
+            plan->gws.p = w; plan->gws.bytes = (size_t)(words * groups) * 4; plan->gws.dev = plan->device;
+            plan->gws_groups = groups; plan->gws_words = words;
+            plan->gcap = (int)gcap; plan->gbcap = (int)gb; plan->gpcap = (int)prev; plan->ghs = (int)hs;
+        }
+        a.in_list = static_cast<const int64_t *>(last == 0 ? plan->ovf1.p : plan->ovf2.p); a.in_count = cnt + last;
+        a.ovf_list = static_cast<int64_t *>(last == 0 ? plan->ovf2.p : plan->ovf1.p); a.ovf_count = cnt + 2;
+        a.gws = static_cast<uint32_t *>(plan->gws.p);
+        a.gws_words_per_group = plan->gws_words; a.gws_groups = plan->gws_groups;
+        a.gcap = plan->gcap; a.ghs = plan->ghs; a.gbcap = plan->gbcap; a.gpcap = plan->gpcap;
+        HIP_TRY(ugs_launch_walk(a, UGS_TIER_G, plan->cus, s, nullptr));
+        last = 2;
+    }
+    HIP_TRY(ugs_launch_scan(static_cast<const uint32_t *>(plan->counts.p), row_count, d_edge_ptr, static_cast<int64_t *>(plan->scantmp.p), s));
+    if (total_edges_host) {
+        uint32_t h[4] = {0, 0, 0, 0};
+        int64_t tot = 0;
+        HIP_TRY(hipMemcpyAsync(&tot, d_edge_ptr + row_count, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h, plan->ovfcnt.p, sizeof(h), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        *total_edges_host = tot;
+        plan->last_overflow = h[0];
+        const bool handled = may_overflow;
+        if ((!handled && h[0] != 0) || (handled && h[last] != 0))
+            return fail(UGS_E_HIP, "internal error: walk rows left unprocessed after the last tier");
+        if (debug_on()) std::fprintf(stderr, "[UGS SAMPLE] rows=%lld k=%d tier=%d overflow=%u/%u/%u edges=%lld\n", (long long)row_count, k, tc.first, h[0], h[1], h[2], (long long)tot);
+    }
+    return UGS_OK;
+}
+
+int ugs_plan_fill(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int64_t row_begin, int64_t row_count,
+                  void *stream, const int64_t *d_nodes, const int64_t *d_edge_ptr, int64_t *d_edge_index, int64_t ld, int64_t *d_edge_src) {
+    if (!plan) return fail(UGS_E_BAD_ARG, "plan is null");
+    if (k < 1 || k > UGS_KMAX) return fail(UGS_E_UNSUPPORTED, "k outside [1, 32]");
+    if (mode < 0 || mode > 2) return fail(UGS_E_BAD_MODE, "mode must be one of: 'sample', 'graph', 'global'");
+    if (row_count <= 0) return UGS_OK;
+    HIP_TRY(hipSetDevice(plan->device));
+    UgsFillArgs a{};
+    a.plan = plan->dev;
+    a.m = m_per_graph; a.k = k; a.mode = mode;
+    a.extra_node_off = extra_node_offset;
+    a.row_begin = row_begin; a.row_count = row_count;
+    a.nodes = d_nodes; a.edge_ptr = d_edge_ptr;
+    a.edge_index = d_edge_index; a.ld = ld; a.edge_src = d_edge_src;
+    const TierChoice tc = choose_tier(plan, k);
+    HIP_TRY(ugs_launch_fill(a, tc.first != UGS_TIER_S, plan->cus, static_cast<hipStream_t>(stream), nullptr));
+    return UGS_OK;
+}
+
+int ugs_plan_last_launch(const ugs_plan *plan, char *name_buf, int name_buf_len, int *grid, int *block, int *lds_bytes, int64_t *overflow_rows) {
+    if (!plan) return fail(UGS_E_BAD_ARG, "plan is null");
+    if (name_buf && name_buf_len > 0) { std::snprintf(name_buf, (size_t)name_buf_len, "%s", plan->last_walk.name ? plan->last_walk.name : ""); }
+    if (grid) *grid = plan->last_walk.grid;
+    if (block) *block = plan->last_walk.block;
+    if (lds_bytes) *lds_bytes = plan->last_walk.lds_bytes;
+    if (overflow_rows) *overflow_rows = plan->last_overflow;
+    return UGS_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// jobs: the two-phase host-facing API (begin = walks + counts, finish = fill + copy-out)
+// ---------------------------------------------------------------------------------------------------------------
+struct ugs_job {
+    ugs_plan *plan = nullptr;
+    DeviceCtx dc;
+    int m = 0, k = 0, mode = 0;
+    int64_t extra = 0, rows = 0, total = 0, G = 0;
+    bool batch = false;
+    PoolBuf nodes, eptr;
+};
+
+namespace {
+void free_job(ugs_job *j) {
+    if (!j) return;
+    pool_put(j->nodes); pool_put(j->eptr);
+    plan_unref(j->plan);
+    delete j;
+}
+
+int begin_common(ugs_plan *plan, int m, int k, int mode, int64_t extra, int seed, bool batch, ugs_job **job_out, int64_t *total_out) {
+    DeviceCtx dc;
+    if (int rc = device_ctx(dc)) { plan_unref(plan); return rc; }
+    auto *j = new ugs_job();
+    j->plan = plan; j->dc = dc; j->m = m; j->k = k; j->mode = mode; j->extra = extra; j->batch = batch;
+    j->G = plan->G;
+    j->rows = plan->G * (int64_t)m;
+    int rc = pool_get((size_t)std::max<int64_t>(j->rows * k, 1) * sizeof(int64_t), dc.id, j->nodes);
+    if (!rc) rc = pool_get((size_t)(j->rows + 1) * sizeof(int64_t), dc.id, j->eptr);
+    if (!rc) rc = ugs_plan_walk(plan, m, k, mode, extra, seed, 0, j->rows, dc.stream, static_cast<int64_t *>(j->nodes.p),
+                                static_cast<int64_t *>(j->eptr.p), &j->total);
+    if (rc) { free_job(j); return rc; }
+    *job_out = j;
+    if (total_out) *total_out = j->total;
+    return UGS_OK;
+}
+
+int finish_common(ugs_job *j, int64_t *nodes, int64_t *edge_index, int64_t *edge_ptr, int64_t *sample_ptr, int64_t *edge_src, int dst_is_device) {
+    hipStream_t s = j->dc.stream;
+    const int64_t rows = j->rows, k = j->k, tot = j->total;
+    int rc = UGS_OK;
+    PoolBuf e_idx, e_src;
+    auto body = [&]() -> int {
+        HIP_TRY(hipSetDevice(j->dc.id));
+        int64_t *d_ei = edge_index, *d_es = edge_src;
+        if (!dst_is_device && tot > 0) {
+            if (int r = pool_get((size_t)(2 * tot) * sizeof(int64_t), j->dc.id, e_idx)) return r;
+            if (int r = pool_get((size_t)tot * sizeof(int64_t), j->dc.id, e_src)) return r;
+            d_ei = static_cast<int64_t *>(e_idx.p); d_es = static_cast<int64_t *>(e_src.p);
+        }
+        if (tot > 0) {
+            if (!d_ei || !d_es) return fail(UGS_E_BAD_ARG, "null edge output pointer");
+            if (int r = ugs_plan_fill(j->plan, j->m, j->k, j->mode, j->extra, 0, rows, s, static_cast<const int64_t *>(j->nodes.p),
+                                      static_cast<const int64_t *>(j->eptr.p), d_ei, tot, d_es)) return r;
+        }
+        const hipMemcpyKind kind = dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        if (rows * k > 0) HIP_TRY(hipMemcpyAsync(nodes, j->nodes.p, (size_t)(rows * k) * sizeof(int64_t), kind, s));
+        HIP_TRY(hipMemcpyAsync(edge_ptr, j->eptr.p, (size_t)(rows + 1) * sizeof(int64_t), kind, s));
+        if (!dst_is_device && tot > 0) {
+            HIP_TRY(hipMemcpyAsync(edge_index, d_ei, (size_t)(2 * tot) * sizeof(int64_t), kind, s));
+            HIP_TRY(hipMemcpyAsync(edge_src, d_es, (size_t)tot * sizeof(int64_t), kind, s));
+        }
+        if (sample_ptr) {
+            std::vector<int64_t> sp((size_t)j->G + 1);
+            for (int64_t g = 0; g <= j->G; ++g) sp[(size_t)g] = g * (int64_t)j->m;
+            if (dst_is_device) HIP_TRY(hipMemcpy(sample_ptr, sp.data(), sp.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+            else std::memcpy(sample_ptr, sp.data(), sp.size() * sizeof(int64_t));
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        return UGS_OK;
+    };
+    rc = body();
+    pool_put(e_idx); pool_put(e_src);
+    free_job(j);
+    return rc;
+}
+}  // namespace
+
+extern "C" {
+
+int ugs_sample_begin(int64_t handle, int m_per_graph, int k, int edge_mode, int64_t base_offset, int seed, ugs_job **job_out, int64_t *total_edges_out) {
+    if (!job_out) return fail(UGS_E_BAD_ARG, "job_out is null");
+    if (edge_mode < 0 || edge_mode > 2) return fail(UGS_E_BAD_MODE, "edge_mode must be one of: 'local', 'flat', 'global'");
+    if (m_per_graph < 0) return fail(UGS_E_BAD_ARG, "m_per_graph must be >= 0");
+    auto g = lookup(handle);
+    if (!g) return fail(UGS_E_INVALID_HANDLE, "Invalid preproc handle");
+    if (g->n == 0) return fail(UGS_E_NO_ROOTS, "No viable roots available");
+    ugs_plan *plan = nullptr;
+    if (int rc = ugs_plan_create_handle(handle, &plan)) return rc;
+    return begin_common(plan, m_per_graph, k, edge_mode, edge_mode == UGS_EDGE_GLOBAL ? base_offset : 0, seed, false, job_out, total_edges_out);
+}
+
+int ugs_sample_finish(ugs_job *job, int64_t *nodes, int64_t *edge_index, int64_t *edge_ptr, int64_t *edge_src, int dst_is_device) {
+    if (!job) return fail(UGS_E_BAD_ARG, "job is null");
+    return finish_common(job, nodes, edge_index, edge_ptr, nullptr, edge_src, dst_is_device);
+}
+
+int ugs_sample_batch_begin(const int64_t *edge_index, int64_t row_stride, int64_t num_cols, const int64_t *ptr, int64_t num_graphs,
+                           int m_per_graph, int k, int mode, int seed, ugs_job **job_out, int64_t *total_edges_out) {
+    if (!job_out) return fail(UGS_E_BAD_ARG, "job_out is null");
+    if (mode < 0 || mode > 2) return fail(UGS_E_BAD_MODE, "mode must be one of: 'sample', 'graph', 'global'");
+    if (m_per_graph < 0) return fail(UGS_E_BAD_ARG, "m_per_graph must be >= 0");
+    if (k < 1) return fail(UGS_E_BAD_ARG, "k must be >= 1");
+    if (k > UGS_KMAX) return fail(UGS_E_UNSUPPORTED, "k > 32 is not supported by the HIP sampler");
+    ugs_plan *plan = nullptr;
+    if (int rc = ugs_plan_create_batch(edge_index, row_stride, num_cols, ptr, num_graphs, k, &plan)) return rc;
+    return begin_common(plan, m_per_graph, k, mode, 0, seed, true, job_out, total_edges_out);
+}
+
+int ugs_sample_batch_finish(ugs_job *job, int64_t *nodes, int64_t *edge_index, int64_t *edge_ptr, int64_t *sample_ptr,
+                            int64_t *edge_src_global, int dst_is_device) {
+    if (!job) return fail(UGS_E_BAD_ARG, "job is null");
+    return finish_common(job, nodes, edge_index, edge_ptr, sample_ptr, edge_src_global, dst_is_device);
+}
+
+int ugs_job_cancel(ugs_job *job) { free_job(job); return UGS_OK; }
+
+}  // extern "C"

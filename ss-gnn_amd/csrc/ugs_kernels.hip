@@ -1,0 +1,632 @@
+// ugs_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the uniform k-subgraph sampler.
+//
+// What is computed (behavioural contract = the reference `ugs_sampler`, AniruddhaMandal/SS-GNN):
+//   walk kernel : per result row b = g*m + i -- xorshift64* stream seeded seed + i*0x9e3779b97f4a7c15
+//                 (reference include/sampler.hpp:26-36, src/sampler.cpp:160), root draw through the alias table or
+//                 the relaxed viable list (src/sampler.cpp:163-173), k-1 growth steps (rand_grow, src/sampler.cpp:36-85),
+//                 per-row induced-edge COUNT; rows come out as nodes[row,k] (-1 padded)
+//   scan kernels: exclusive prefix sum of the counts -> edge_ptr
+//   fill kernel : induced edges of every complete row in the reference's order (vertex j, then CSR position p;
+//                 src/sampler.cpp:232-243) with the endpoint numbering of the requested mode (src/sampler.cpp:258-281)
+//
+// How (MI355X-first, nothing translated from the reference's std::unordered_set code):
+//   * a walk is owned by a GROUP of GS lanes of one 64-lane wavefront (GS = 8 for TU-sized graphs: 8 walks per
+//     wave; GS = 64 for large graphs: the wave reads a whole adjacency row with one coalesced 8-byte-per-lane load).
+//   * all per-walk state (candidate list D, membership hash, ordered prefixes, bucket table) lives in LDS; groups are
+//     independent, so there is no __syncthreads anywhere -- lanes of a group run in lock-step inside their wave.
+//   * the reference picks `cut[rng % |cut|]` where `cut` is the ITERATION ORDER of a libstdc++ unordered_set<int>
+//     rebuilt at every step.  That order is reproduced without any linked list: D keeps the distinct candidates in
+//     first-insertion order (incrementally: drop the chosen vertex, append the new vertex's unseen neighbours), and
+//     the container's order is a staged stable grouping computed data-parallel per stage of the bucket chain
+//     13 -> 29 -> 59 -> ... : "peel rounds" of one LDS atomicMax per element give every element its position inside
+//     its bucket and every bucket its size and first element; a group-wide suffix scan of the bucket sizes gives each
+//     bucket's start; rank = start + position.  Only the last stage needs no materialisation: the lane whose rank
+//     equals rng % |cut| holds the answer.
+//   * the neighbour's order rank is stored next to the neighbour id in HBM (int2 adjacency), so the suffix filter is
+//     free; root records pack the alias row and both candidate root vertices in 24 bytes.
+//   * ballot + popcount prefix sums compact new candidates into D and (fill kernel) edges into the output.
+#include "ugs_device.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------
+// bucket chain of a libstdc++ unordered_set grown from empty by single inserts (max load factor 1), with the
+// multiply-shift constants of an exact x / B for 0 <= x < 2^31:  q = umulhi(x, M) >> (S - 1),
+// M = floor(2^(31+S) / B) + 1, S = ceil(log2 B).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kChainLen = 27;
+constexpr uint32_t kChainHost[kChainLen] = {13u, 29u, 59u, 127u, 257u, 541u, 1109u, 2357u, 5087u, 10273u, 20753u, 42043u,
+    85229u, 172933u, 351061u, 712697u, 1447153u, 2938679u, 5967347u, 12117689u, 24607243u, 49969847u, 101473717u,
+    206062531u, 418451333u, 849749479u, 1725587117u};
+
+constexpr int clog2(uint32_t b) { int s = 0; while ((1ull << s) < b) ++s; return s; }
+constexpr uint32_t cmagic(uint32_t b) { return (uint32_t)(((1ull << (31 + clog2(b))) / b) + 1ull); }
+
+struct ChainTab { uint32_t B[kChainLen]; uint32_t M[kChainLen]; uint32_t S[kChainLen]; };
+constexpr ChainTab make_chain() {
+    ChainTab t{};
+    for (int i = 0; i < kChainLen; ++i) { t.B[i] = kChainHost[i]; t.M[i] = cmagic(kChainHost[i]); t.S[i] = (uint32_t)clog2(kChainHost[i]) - 1u; }
+    return t;
+}
+__constant__ ChainTab d_chain = make_chain();
+
+__device__ __forceinline__ uint32_t mod_magic(uint32_t x, uint32_t B, uint32_t M, uint32_t S) {
+    uint32_t q = __umulhi(x, M) >> S;
+    return x - q * B;
+}
+
+// xorshift64* (reference include/sampler.hpp:26-36)
+struct Rng {
+    uint64_t s;
+    __device__ __forceinline__ void init(uint64_t seed) { s = seed ? seed : 1ull; }
+    __device__ __forceinline__ uint64_t next() {
+        uint64_t x = s;
+        x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+        s = x;
+        return x * 2685821657736338717ull;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// sub-wave group of GS lanes
+// ------------------------------------------------------------------------------------------------------------------
+template <int GS> struct Grp {
+    int lane;    // 0..GS-1
+    int gbase;   // first wave lane of this group
+    __device__ __forceinline__ void init() {
+        int wl = (int)(threadIdx.x & 63);
+        lane = wl & (GS - 1);
+        gbase = wl & ~(GS - 1);
+    }
+    __device__ __forceinline__ uint64_t ballot(bool p) const {
+        uint64_t m = __ballot(p);
+        if (GS == 64) return m;
+        return (m >> gbase) & ((1ull << (GS & 63)) - 1ull);
+    }
+    __device__ __forceinline__ bool any(bool p) const { return ballot(p) != 0ull; }
+    __device__ __forceinline__ uint64_t lt_mask() const { return (1ull << lane) - 1ull; }
+    template <class T> __device__ __forceinline__ T bcast(T v, int src) const { return __shfl(v, gbase + src, 64); }
+    // inclusive suffix sum over the group's lanes: sum of x over lanes >= lane
+    __device__ __forceinline__ uint32_t suffix_incl(uint32_t x) const {
+#pragma unroll
+        for (int d = 1; d < GS; d <<= 1) {
+            uint32_t y = __shfl_down(x, d, GS);
+            if (lane + d < GS) x += y;
+        }
+        return x;
+    }
+};
+
+// memory-space policies of the per-walk workspace --------------------------------------------------------------------
+struct LdsSpace {       // LDS: one wave's LDS operations are serviced in issue order; only the compiler must be fenced
+    using TW = uint32_t; using TA = uint16_t;
+    static constexpr int SH = 16;
+    static constexpr TW PMASK = 0xFFFFu, FLAG = 0x80000000u;
+    static constexpr TA UNASSIGNED = 0xFFFFu;
+    static __device__ __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+};
+struct GlbSpace {       // global-memory fallback: agent-scope fence between phases (rare, correctness-first tier)
+    using TW = unsigned long long; using TA = uint32_t;
+    static constexpr int SH = 32;
+    static constexpr TW PMASK = 0xFFFFFFFFull, FLAG = 1ull << 63;
+    static constexpr TA UNASSIGNED = 0xFFFFFFFFu;
+    static __device__ __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __builtin_amdgcn_wave_barrier(); }
+};
+
+template <class SP> struct Work {
+    uint32_t *D;             // distinct candidates, first-insertion order           [cap]
+    uint32_t *SA, *SB;       // ordered prefixes (ping-pong)                         [pcap]
+    typename SP::TA *AUX;    // per element: position inside its bucket              [cap]
+    typename SP::TW *TBL;    // per bucket: (round|pos) -> (size|first) -> start     [bcap]
+    uint32_t *HK, *HP;       // membership hash: key / (local index in sample | first-seen sequence number)  [hs]
+    uint32_t cap, hmask, hlimit;
+};
+
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t hash_slot(uint32_t w, uint32_t mask) { return (w * 2654435761u >> 7) & mask; }
+
+// iteration-order selection: vertex at position `rsel` of the libstdc++ unordered_set<int> built by inserting
+// D[0..c) one by one (see file header).  c >= 1, rsel < c.  Group-uniform result.
+template <int GS, class SP>
+__device__ __forceinline__ uint32_t select_in_order(const Work<SP> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel) {
+    using TW = typename SP::TW;
+    using TA = typename SP::TA;
+    uint32_t *OLD = ws.SA, *NEW = ws.SB;
+    uint32_t n_old = 0;
+    for (int stage = 0; stage < kChainLen; ++stage) {     // terminates at the first chain value >= c
+        const uint32_t B = d_chain.B[stage], M = d_chain.M[stage], S = d_chain.S[stage];
+        const uint32_t L = c < B ? c : B;
+        const bool final = c <= B;
+        for (uint32_t b = g.lane; b < B; b += GS) ws.TBL[b] = 0;
+        for (uint32_t t = g.lane; t < L; t += GS) ws.AUX[t] = SP::UNASSIGNED;
+        SP::sync();
+        // peel rounds: in round r the still-unplaced element with the largest position wins its bucket
+        for (uint32_t round = 1; round <= L; ++round) {        // at most (largest bucket size) <= L rounds
+            for (uint32_t t = g.lane; t < L; t += GS) {
+                if (ws.AUX[t] == SP::UNASSIGNED) {
+                    uint32_t key = (t < n_old) ? OLD[t] : ws.D[t];
+                    uint32_t b = mod_magic(key, B, M, S);
+                    atomicMax(&ws.TBL[b], ((TW)round << SP::SH) | (TW)t);
+                }
+            }
+            SP::sync();
+            bool left = false;
+            for (uint32_t t = g.lane; t < L; t += GS) {
+                if (ws.AUX[t] == SP::UNASSIGNED) {
+                    uint32_t key = (t < n_old) ? OLD[t] : ws.D[t];
+                    uint32_t b = mod_magic(key, B, M, S);
+                    if ((uint32_t)(ws.TBL[b] & SP::PMASK) == t) ws.AUX[t] = (TA)(round - 1);
+                    else left = true;
+                }
+            }
+            SP::sync();
+            if (!g.any(left)) break;
+        }
+        // now TBL[b] = (bucket size << SH) | first position.  Buckets are laid out by DESCENDING first position:
+        // suffix scan of the sizes over the positions, highest chunk first; the leader converts its bucket entry to the
+        // bucket's start rank (it is the last element of its bucket to be visited).
+        uint32_t carry = 0;
+        const int nchunks = (int)((L + GS - 1) / GS);
+        for (int ch = nchunks - 1; ch >= 0; --ch) {
+            const uint32_t t = (uint32_t)ch * GS + g.lane;
+            const bool in = t < L;
+            uint32_t b = 0, gsz = 0;
+            bool leader = false;
+            if (in) {
+                uint32_t key = (t < n_old) ? OLD[t] : ws.D[t];
+                b = mod_magic(key, B, M, S);
+                TW v = ws.TBL[b];
+                leader = !(v & SP::FLAG) && (uint32_t)(v & SP::PMASK) == t;
+                gsz = leader ? (uint32_t)(v >> SP::SH) : 0u;
+            }
+            uint32_t incl = g.suffix_incl(gsz);
+            uint32_t excl = incl - gsz + carry;
+            carry += g.bcast(incl, 0);
+            if (leader) ws.TBL[b] = SP::FLAG | (TW)excl;
+            SP::sync();
+        }
+        // rank = bucket start + position inside the bucket
+        bool have = false;
+        uint32_t mine = 0;
+        for (uint32_t t = g.lane; t < L; t += GS) {
+            uint32_t key = (t < n_old) ? OLD[t] : ws.D[t];
+            uint32_t b = mod_magic(key, B, M, S);
+            uint32_t rank = (uint32_t)(ws.TBL[b] & ~SP::FLAG) + (uint32_t)ws.AUX[t];
+            if (final) { if (rank == rsel) { have = true; mine = key; } }
+            else NEW[rank] = key;
+        }
+        SP::sync();
+        if (final) {
+            uint64_t mk = g.ballot(have);
+            int src = mk ? (__ffsll((long long)mk) - 1) : 0;
+            return g.bcast(mine, src);
+        }
+        uint32_t *tmp = OLD; OLD = NEW; NEW = tmp;
+        n_old = L;
+    }
+    return ws.D[0];   // unreachable for c within the chain
+}
+
+// Adjacency row of the vertex just added to the sample (local index size-1):
+//   - counts the induced-edge entries it contributes (entries to earlier members count twice: the symmetric CSR holds
+//     the mirror entry in the earlier member's row; entries to itself count once),
+//   - ADD: appends neighbours that pass the suffix filter and were never seen to D (first-occurrence order).
+// Returns false when the walk outgrew this tier's workspace.
+template <int GS, class SP, bool ADD>
+__device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, const UgsPlanDev &P, int64_t rbase, uint32_t v,
+                                         uint32_t root_vi, uint32_t size, uint32_t &c, uint32_t &hcount, uint32_t &seq,
+                                         uint32_t &ecount) {
+    const int64_t r0 = P.rowptr[rbase + v], r1 = P.rowptr[rbase + v + 1];
+    for (int64_t base = r0; base < r1; base += GS) {
+        const int64_t p = base + g.lane;
+        bool cand = false;
+        uint32_t w = 0;
+        if (p < r1) {
+            int2 e = P.adj[p];
+            w = (uint32_t)e.x;
+            cand = (uint32_t)e.y >= root_vi;
+        }
+        uint32_t val = kEmpty;
+        uint32_t slot = hash_slot(w, ws.hmask);
+        const uint32_t myseq = seq + g.lane;
+        if (ADD) {
+            if (hcount + (uint32_t)__popcll(g.ballot(cand)) > ws.hlimit) return false;
+            if (cand) {
+                for (uint32_t it = 0; it <= ws.hmask; ++it) {       // the table is never more than 3/4 full
+                    uint32_t old = atomicCAS(&ws.HK[slot], kEmpty, w);
+                    if (old == kEmpty || old == w) break;
+                    slot = (slot + 1) & ws.hmask;
+                }
+                atomicMin(&ws.HP[slot], myseq);
+            }
+            SP::sync();
+            if (cand) val = ws.HP[slot];
+        } else {
+            if (cand) {
+                for (uint32_t it = 0; it <= ws.hmask; ++it) {
+                    uint32_t cur = ws.HK[slot];
+                    if (cur == w) { val = ws.HP[slot]; break; }
+                    if (cur == kEmpty) break;
+                    slot = (slot + 1) & ws.hmask;
+                }
+            }
+        }
+        // HP < UGS_KMAX: member of the sample, value = its local index
+        ecount += 2u * (uint32_t)__popcll(g.ballot(val < size - 1)) + (uint32_t)__popcll(g.ballot(val == size - 1));
+        if (ADD) {
+            const bool first = cand && val == myseq;
+            const uint64_t fm = g.ballot(first);
+            const uint32_t nnew = (uint32_t)__popcll(fm);
+            if (c + nnew > ws.cap) return false;
+            if (first) ws.D[c + (uint32_t)__popcll(fm & g.lt_mask())] = w;
+            c += nnew;
+            hcount += nnew;
+            seq += GS;
+            SP::sync();
+        }
+    }
+    return true;
+}
+
+// One walk.  Returns false on workspace overflow (the row is then redone by the next tier).
+template <int GS, class SP>
+__device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, const UgsWalkArgs &a, int64_t row_rel,
+                                        uint32_t *SV /* [UGS_KMAX] group-private */) {
+    const UgsPlanDev &P = a.plan;
+    const int64_t row = a.row_begin + row_rel;
+    int64_t gi, i;
+    if (P.num_graphs == 1) { gi = 0; i = row; }
+    else { gi = row / a.m; i = row - gi * a.m; }
+    const UgsGraphDesc gd = P.graphs[gi];
+    const int k = a.k;
+    int64_t *out = a.nodes + row_rel * k;
+    if (gd.level < 0) {   // degenerate graph: m rows of -1, no edges (reference src/ugs_sampler_batch_extension.cpp:132-143)
+        for (int j = g.lane; j < k; j += GS) out[j] = -1;
+        if (g.lane == 0) a.counts[row_rel] = 0;
+        return true;
+    }
+    Rng rng;
+    rng.init(a.seed64 + (uint64_t)i * 0x9e3779b97f4a7c15ull);
+    uint32_t root_vi, root_v;
+    if (gd.level == 0) {      // alias draw: two numbers (reference include/sampler.hpp:72-77)
+        uint32_t j = (uint32_t)(rng.next() % (uint64_t)(uint32_t)gd.n);
+        double u = (double)rng.next() * 0x1p-64;   // == / (double)UINT64_MAX (which is 2^64): exact scaling
+        const UgsRootRec rr = P.roots[gd.vbase + j];
+        const bool self = u < rr.prob;
+        root_vi = self ? j : (uint32_t)rr.alias;
+        root_v = (uint32_t)(self ? rr.v_self : rr.v_alias);
+    } else {                  // relaxed: uniform over the viable list, one number (reference src/sampler.cpp:169-172)
+        uint32_t idx = (uint32_t)(rng.next() % (uint64_t)(uint32_t)gd.n_viable);
+        int2 vr = P.viable[gd.viable_base + idx];
+        root_vi = (uint32_t)vr.x;
+        root_v = (uint32_t)vr.y;
+    }
+    // reset the membership hash
+    for (uint32_t s = g.lane; s <= ws.hmask; s += GS) { ws.HK[s] = kEmpty; ws.HP[s] = kEmpty; }
+    SP::sync();
+    if (g.lane == 0) { uint32_t s = hash_slot(root_v, ws.hmask); ws.HK[s] = root_v; ws.HP[s] = 0; SV[0] = root_v; }
+    SP::sync();
+    uint32_t size = 1, c = 0, hcount = 1, seq = UGS_KMAX, ecount = 0;
+    bool ok = (k > 1) ? scan_row<GS, SP, true>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, seq, ecount)
+                      : scan_row<GS, SP, false>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, seq, ecount);
+    if (!ok) return false;
+    for (int step = 1; step < k; ++step) {
+        if (c == 0) break;                                                    // growth failed: partial row
+        const uint32_t rsel = (uint32_t)(rng.next() % (uint64_t)c);
+        const uint32_t w = select_in_order<GS, SP>(ws, g, c, rsel);
+        // move w from the candidates to the sample: drop it from D keeping the order of the others
+        uint32_t q = c;
+        for (uint32_t t0 = 0; t0 < c; t0 += GS) {
+            uint32_t t = t0 + g.lane;
+            uint64_t mk = g.ballot(t < c && ws.D[t] == w);
+            if (mk) { q = t0 + (uint32_t)(__ffsll((long long)mk) - 1); break; }
+        }
+        for (uint32_t t0 = q; t0 + 1 < c; t0 += GS) {
+            uint32_t t = t0 + g.lane;
+            uint32_t x = (t + 1 < c) ? ws.D[t + 1] : 0u;
+            SP::sync();
+            if (t + 1 < c) ws.D[t] = x;
+            SP::sync();
+        }
+        c -= 1;
+        if (g.lane == 0) {
+            uint32_t s = hash_slot(w, ws.hmask);
+            for (uint32_t it = 0; it <= ws.hmask && ws.HK[s] != w; ++it) s = (s + 1) & ws.hmask;
+            ws.HP[s] = size;          // local index in the sample
+            SV[size] = w;
+        }
+        size += 1;
+        SP::sync();
+        ok = (step < k - 1) ? scan_row<GS, SP, true>(ws, g, P, gd.rbase, w, root_vi, size, c, hcount, seq, ecount)
+                            : scan_row<GS, SP, false>(ws, g, P, gd.rbase, w, root_vi, size, c, hcount, seq, ecount);
+        if (!ok) return false;
+    }
+    // nodes row: growth order, -1 padded (reference src/sampler.cpp:205-216, src/ugs_sampler_batch_extension.cpp:188-196)
+    const int64_t off = gd.node_lo + a.extra_node_off;
+    for (int j = g.lane; j < k; j += GS) out[j] = (j < (int)size) ? (int64_t)SV[j] + off : (int64_t)-1;
+    if (g.lane == 0) a.counts[row_rel] = (size == (uint32_t)k) ? ecount : 0u;   // incomplete rows carry no edges (:219-223)
+    return true;
+}
+
+// LDS words of one group's workspace for a tier
+template <int CAP> struct TierCfg {
+    static constexpr int PCAP = CAP <= 64 ? 59 : (CAP <= 512 ? 257 : 1109);      // largest chain value < CAP
+    static constexpr int BCAP = CAP <= 64 ? 127 : (CAP <= 512 ? 541 : 2357);     // smallest chain value >= CAP
+    static constexpr int HS = CAP <= 64 ? 128 : (CAP <= 512 ? 1024 : 4096);
+    static constexpr int PCAP_A = (PCAP + 1) & ~1, BCAP_A = (BCAP + 1) & ~1;
+    static constexpr int WORDS = CAP /*D*/ + 2 * PCAP_A /*SA,SB*/ + CAP / 2 /*AUX u16*/ + BCAP_A /*TBL*/ + 2 * HS /*HK,HP*/ + UGS_KMAX /*SV*/;
+};
+
+template <int GS, int CAP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void ugs_walk_lds(UgsWalkArgs a) {
+    using Cfg = TierCfg<CAP>;
+    constexpr int GROUPS = BLOCK / GS;
+    __shared__ uint32_t lds[GROUPS * Cfg::WORDS];
+    Grp<GS> g;
+    g.init();
+    const int gib = (int)threadIdx.x / GS;
+    uint32_t *base = lds + gib * Cfg::WORDS;
+    Work<LdsSpace> ws;
+    ws.D = base;
+    ws.SA = ws.D + CAP;
+    ws.SB = ws.SA + Cfg::PCAP_A;
+    ws.AUX = (uint16_t *)(ws.SB + Cfg::PCAP_A);
+    ws.TBL = ws.SB + Cfg::PCAP_A + CAP / 2;
+    ws.HK = ws.TBL + Cfg::BCAP_A;
+    ws.HP = ws.HK + Cfg::HS;
+    uint32_t *SV = ws.HP + Cfg::HS;
+    ws.cap = CAP;
+    ws.hmask = Cfg::HS - 1;
+    ws.hlimit = Cfg::HS / 4 * 3;
+    const int64_t total = a.in_list ? (int64_t)*a.in_count : a.row_count;
+    const int64_t ngroups = (int64_t)gridDim.x * GROUPS;
+    for (int64_t it = (int64_t)blockIdx.x * GROUPS + gib; it < total; it += ngroups) {
+        const int64_t row_rel = a.in_list ? a.in_list[it] : it;
+        if (!do_walk<GS, LdsSpace>(ws, g, a, row_rel, SV)) {
+            if (g.lane == 0) { uint32_t pos = atomicAdd(a.ovf_count, 1u); a.ovf_list[pos] = row_rel; }
+        }
+    }
+}
+
+// last tier: workspace in global memory, one wave per walk, any candidate-set size up to gcap
+__global__ __launch_bounds__(64) void ugs_walk_global(UgsWalkArgs a) {
+    __shared__ uint32_t SV[UGS_KMAX];
+    Grp<64> g;
+    g.init();
+    uint32_t *base = a.gws + (int64_t)blockIdx.x * a.gws_words_per_group;
+    Work<GlbSpace> ws;
+    const int64_t pc = ((int64_t)a.gpcap + 1) & ~1ll;
+    ws.TBL = (unsigned long long *)base;                         // 8-byte aligned first
+    ws.D = base + 2 * (((int64_t)a.gbcap + 1) & ~1ll);
+    ws.SA = ws.D + (((int64_t)a.gcap + 1) & ~1ll);
+    ws.SB = ws.SA + pc;
+    ws.AUX = ws.SB + pc;
+    ws.HK = ws.AUX + (((int64_t)a.gcap + 1) & ~1ll);
+    ws.HP = ws.HK + a.ghs;
+    ws.cap = (uint32_t)a.gcap;
+    ws.hmask = (uint32_t)a.ghs - 1u;
+    ws.hlimit = (uint32_t)a.ghs / 4u * 3u;
+    const int64_t total = a.in_list ? (int64_t)*a.in_count : a.row_count;
+    for (int64_t it = blockIdx.x; it < total; it += gridDim.x) {
+        const int64_t row_rel = a.in_list ? a.in_list[it] : it;
+        if (!do_walk<64, GlbSpace>(ws, g, a, row_rel, SV)) {
+            // cannot happen when gcap covers the graph's bound; mark the row so the host can report it
+            if (g.lane == 0) { uint32_t pos = atomicAdd(a.ovf_count, 1u); a.ovf_list[pos] = row_rel; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// exclusive scan of the per-row counts -> edge_ptr[rows + 1]
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kScanBlock = 256, kScanPer = 8, kScanTile = kScanBlock * kScanPer;
+
+__device__ __forceinline__ int64_t block_excl_scan(int64_t x, int64_t *total, int64_t *sh /* [kScanBlock/64] */) {
+    // inclusive scan inside the wave, then across the 4 waves
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    long long incl = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { long long y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+    if (lane == 63) sh[wv] = incl;
+    __syncthreads();
+    int64_t woff = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < kScanBlock / 64; ++i) { if (i < wv) woff += sh[i]; tot += sh[i]; }
+    __syncthreads();
+    *total = tot;
+    return woff + incl - x;
+}
+
+__global__ __launch_bounds__(kScanBlock) void ugs_scan_partials(const uint32_t *counts, int64_t rows, int64_t *block_sums) {
+    __shared__ int64_t sh[kScanBlock / 64];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanPer;
+    int64_t s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) if (base + j < rows) s += counts[base + j];
+    int64_t tot;
+    block_excl_scan(s, &tot, sh);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kScanBlock) void ugs_scan_block_sums(int64_t *block_sums, int64_t nblocks) {
+    __shared__ int64_t sh[kScanBlock / 64];
+    int64_t carry = 0;
+    for (int64_t base = 0; base < nblocks; base += kScanBlock) {
+        const int64_t idx = base + threadIdx.x;
+        int64_t x = idx < nblocks ? block_sums[idx] : 0, tot;
+        int64_t ex = block_excl_scan(x, &tot, sh);
+        if (idx < nblocks) block_sums[idx] = carry + ex;
+        carry += tot;
+    }
+}
+
+__global__ __launch_bounds__(kScanBlock) void ugs_scan_final(const uint32_t *counts, int64_t rows, const int64_t *block_offs,
+                                                             int64_t *edge_ptr) {
+    __shared__ int64_t sh[kScanBlock / 64];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanPer;
+    uint32_t v[kScanPer];
+    int64_t s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) { v[j] = (base + j < rows) ? counts[base + j] : 0u; s += v[j]; }
+    int64_t tot;
+    int64_t ex = block_excl_scan(s, &tot, sh) + (block_offs ? block_offs[blockIdx.x] : 0);
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) { if (base + j < rows) edge_ptr[base + j] = ex; ex += v[j]; }
+    if (rows - 1 >= base && rows - 1 < base + kScanPer) edge_ptr[rows] = ex;   // owner of the last row writes the total
+}
+
+// single-block variant for small row counts (one launch instead of three)
+__global__ __launch_bounds__(kScanBlock) void ugs_scan_small(const uint32_t *counts, int64_t rows, int64_t *edge_ptr) {
+    __shared__ int64_t sh[kScanBlock / 64];
+    int64_t carry = 0;
+    for (int64_t tile = 0; tile < rows; tile += kScanTile) {
+        const int64_t base = tile + (int64_t)threadIdx.x * kScanPer;
+        uint32_t v[kScanPer];
+        int64_t s = 0;
+#pragma unroll
+        for (int j = 0; j < kScanPer; ++j) { v[j] = (base + j < rows) ? counts[base + j] : 0u; s += v[j]; }
+        int64_t tot;
+        int64_t ex = carry + block_excl_scan(s, &tot, sh);
+#pragma unroll
+        for (int j = 0; j < kScanPer; ++j) { if (base + j < rows) edge_ptr[base + j] = ex; ex += v[j]; }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) edge_ptr[rows] = carry;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// fill kernel: induced edges of complete rows, vertex order j then CSR position p (reference src/sampler.cpp:232-243)
+// ------------------------------------------------------------------------------------------------------------------
+template <int GS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
+    constexpr int GROUPS = BLOCK / GS;
+    __shared__ uint32_t sv_all[GROUPS * UGS_KMAX];
+    Grp<GS> g;
+    g.init();
+    const int gib = (int)threadIdx.x / GS;
+    uint32_t *SV = sv_all + gib * UGS_KMAX;
+    const UgsPlanDev &P = a.plan;
+    const int k = a.k;
+    const int64_t ngroups = (int64_t)gridDim.x * GROUPS;
+    for (int64_t row_rel = (int64_t)blockIdx.x * GROUPS + gib; row_rel < a.row_count; row_rel += ngroups) {
+        const int64_t e0 = a.edge_ptr[row_rel], e1 = a.edge_ptr[row_rel + 1];
+        if (e1 == e0) continue;                               // incomplete or edgeless row
+        const int64_t row = a.row_begin + row_rel;
+        int64_t gi, i;
+        if (P.num_graphs == 1) { gi = 0; i = row; }
+        else { gi = row / a.m; i = row - gi * a.m; }
+        const UgsGraphDesc gd = P.graphs[gi];
+        const int64_t off = gd.node_lo + a.extra_node_off;
+        const int64_t *nrow = a.nodes + row_rel * k;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        for (int j = g.lane; j < k; j += GS) SV[j] = (uint32_t)(nrow[j] - off);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        int64_t w_off = e0;
+        for (int j = 0; j < k; ++j) {
+            const uint32_t u = SV[j];
+            const int64_t r0 = P.rowptr[gd.rbase + u], r1 = P.rowptr[gd.rbase + u + 1];
+            for (int64_t base = r0; base < r1; base += GS) {
+                const int64_t p = base + g.lane;
+                int l = -1;
+                if (p < r1) {
+                    const uint32_t w = (uint32_t)P.adj[p].x;
+                    for (int t = 0; t < k; ++t) if (SV[t] == w) { l = t; break; }
+                }
+                const uint64_t mk = g.ballot(l >= 0);
+                if (l >= 0) {
+                    const int64_t pos = w_off + __popcll(mk & g.lt_mask());
+                    int64_t uf, vf;
+                    if (a.mode == 0) { uf = j; vf = l; }
+                    else if (a.mode == 1) { uf = i * k + j; vf = i * k + l; }
+                    else { uf = nrow[j]; vf = nrow[l]; }
+                    a.edge_index[pos] = uf;
+                    a.edge_index[a.ld + pos] = vf;
+                    a.edge_src[pos] = (int64_t)P.ecol[p];
+                }
+                w_off += __popcll(mk);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------------------
+int64_t ugs_scan_tmp_words(int64_t rows) { return (rows + kScanTile - 1) / kScanTile + 1; }
+
+int64_t ugs_global_ws_words(int64_t gcap, int64_t gbcap, int64_t gpcap, int64_t ghs) {
+    auto ev = [](int64_t x) { return (x + 1) & ~1ll; };
+    return 2 * ev(gbcap) + ev(gcap) + 2 * ev(gpcap) + ev(gcap) + 2 * ghs;
+}
+
+uint32_t ugs_chain_value(int idx) { return (idx >= 0 && idx < kChainLen) ? kChainHost[idx] : 0u; }
+
+uint32_t ugs_chain_at_least(int64_t c, int *index_out) {   // smallest chain value >= c
+    for (int i = 0; i < kChainLen; ++i) if ((int64_t)kChainHost[i] >= c) { if (index_out) *index_out = i; return kChainHost[i]; }
+    if (index_out) *index_out = -1;
+    return 0;
+}
+
+template <int GS, int CAP, int BLOCK>
+static hipError_t launch_lds(const UgsWalkArgs &a, int cus, int blocks_per_cu, hipStream_t s, UgsLaunchInfo *info, const char *name) {
+    constexpr int GROUPS = BLOCK / GS;
+    const int64_t work = a.in_list ? (int64_t)cus * blocks_per_cu * GROUPS : a.row_count;   // list length unknown on the host
+    int64_t grid = (work + GROUPS - 1) / GROUPS;
+    const int64_t cap = (int64_t)cus * blocks_per_cu;
+    if (grid > cap) grid = cap;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((ugs_walk_lds<GS, CAP, BLOCK>), dim3((unsigned)grid), dim3(BLOCK), 0, s, a);
+    if (info) { info->name = name; info->grid = (int)grid; info->block = BLOCK; info->lds_bytes = GROUPS * TierCfg<CAP>::WORDS * 4; }
+    return hipGetLastError();
+}
+
+hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, hipStream_t s, UgsLaunchInfo *info) {
+    if (cus <= 0) cus = 256;
+    switch (tier) {
+    case UGS_TIER_S: return launch_lds<8, 64, 256>(a, cus, 2, s, info, "ugs_walk_lds<8,64>");
+    case UGS_TIER_M: return launch_lds<64, 512, 64>(a, cus, 10, s, info, "ugs_walk_lds<64,512>");
+    case UGS_TIER_L: return launch_lds<64, 2048, 64>(a, cus, 2, s, info, "ugs_walk_lds<64,2048>");
+    default: {
+        int64_t grid = a.gws_words_per_group > 0 ? a.gws_groups : 0;
+        if (grid < 1) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(ugs_walk_global, dim3((unsigned)grid), dim3(64), 0, s, a);
+        if (info) { info->name = "ugs_walk_global"; info->grid = (int)grid; info->block = 64; info->lds_bytes = UGS_KMAX * 4; }
+        return hipGetLastError();
+    }
+    }
+}
+
+hipError_t ugs_launch_scan(const uint32_t *counts, int64_t rows, int64_t *edge_ptr, int64_t *block_tmp, hipStream_t s) {
+    if (rows <= 0) { return hipMemsetAsync(edge_ptr, 0, sizeof(int64_t), s); }
+    if (rows <= 16 * kScanTile) {
+        hipLaunchKernelGGL(ugs_scan_small, dim3(1), dim3(kScanBlock), 0, s, counts, rows, edge_ptr);
+        return hipGetLastError();
+    }
+    const int64_t nb = (rows + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(ugs_scan_partials, dim3((unsigned)nb), dim3(kScanBlock), 0, s, counts, rows, block_tmp);
+    hipLaunchKernelGGL(ugs_scan_block_sums, dim3(1), dim3(kScanBlock), 0, s, block_tmp, nb);
+    hipLaunchKernelGGL(ugs_scan_final, dim3((unsigned)nb), dim3(kScanBlock), 0, s, counts, rows, (const int64_t *)block_tmp, edge_ptr);
+    return hipGetLastError();
+}
+
+hipError_t ugs_launch_fill(const UgsFillArgs &a, int wide, int cus, hipStream_t s, UgsLaunchInfo *info) {
+    if (a.row_count <= 0) return hipSuccess;
+    if (cus <= 0) cus = 256;
+    if (wide) {
+        constexpr int BLOCK = 256, GROUPS = 4;
+        int64_t grid = (a.row_count + GROUPS - 1) / GROUPS;
+        if (grid > (int64_t)cus * 8) grid = (int64_t)cus * 8;
+        hipLaunchKernelGGL((ugs_fill<64, BLOCK>), dim3((unsigned)grid), dim3(BLOCK), 0, s, a);
+        if (info) { info->name = "ugs_fill<64>"; info->grid = (int)grid; info->block = BLOCK; info->lds_bytes = GROUPS * UGS_KMAX * 4; }
+    } else {
+        constexpr int BLOCK = 256, GROUPS = 32;
+        int64_t grid = (a.row_count + GROUPS - 1) / GROUPS;
+        if (grid > (int64_t)cus * 8) grid = (int64_t)cus * 8;
+        hipLaunchKernelGGL((ugs_fill<8, BLOCK>), dim3((unsigned)grid), dim3(BLOCK), 0, s, a);
+        if (info) { info->name = "ugs_fill<8>"; info->grid = (int)grid; info->block = BLOCK; info->lds_bytes = GROUPS * UGS_KMAX * 4; }
+    }
+    return hipGetLastError();
+}

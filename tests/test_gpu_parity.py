@@ -1,0 +1,209 @@
+"""GPU: the HIP product (through the C ABI, via the ugs_sampler drop-in package) against
+  (1) the committed golden fixtures generated from the reference, and
+  (2) the CPU oracle on seeded random inputs at sizes the oracle finishes in seconds.
+Bit-exact: every output is an integer tensor."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import scenarios as sc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def product():
+    from backends import ProductBackend
+    return ProductBackend()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from backends import OracleBackend
+    return OracleBackend()
+
+
+@pytest.mark.parametrize("name", sorted(sc.SCENARIOS))
+def test_product_reproduces_golden(name, product):
+    calls, expected = sc.load_golden(name)
+    got = sc.run_scenario(calls, product)
+    sc.check_against_golden(calls, expected, got, f"HIP vs golden {name}")
+
+
+def _rand_batch(rng, sizes, ps):
+    G = rng.randint(1, 6)
+    cols, ptr = [], [0]
+    for _ in range(G):
+        n = rng.choice(sizes)
+        off = ptr[-1]
+        p = rng.choice(ps)
+        e = [(u + off, v + off) for u in range(n) for v in range(u + 1, n) if rng.random() < p]
+        if n and rng.random() < 0.2:
+            e.append((off + rng.randrange(n),) * 2)
+        if rng.random() < 0.5:
+            e = e + [(v, u) for u, v in e]
+        cols += e
+        ptr.append(off + n)
+    if rng.random() < 0.3:
+        rng.shuffle(cols)
+    return np.array(cols, dtype=np.int64).T.reshape(2, -1), np.array(ptr, dtype=np.int64)
+
+
+def _same(calls, product, orc, what):
+    got = sc.run_scenario(calls, product)
+    want = sc.run_scenario(calls, orc)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert type(g) is type(w), f"{what}: call {i}: {g!r} vs {w!r}"
+        if isinstance(g, tuple) and g and isinstance(g[0], str):
+            assert w[1] in g[1] or g[1] in w[1], f"{what}: call {i}: error text {g[1]!r} vs {w[1]!r}"
+        elif isinstance(g, tuple):
+            for j, (a, b) in enumerate(zip(g, w)):
+                assert a.shape == b.shape and np.array_equal(a, b), f"{what}: call {i} output {j} differs"
+        elif isinstance(g, dict):
+            assert g == w
+
+
+def test_random_batches_vs_oracle(product, orc):
+    rng = random.Random(31337)
+    calls = []
+    for _ in range(60):
+        ei, ptr = _rand_batch(rng, [0, 1, 2, 3, 5, 8, 12, 20, 40], [0.1, 0.3, 0.7])
+        calls.append(dict(fn="sample_batch", edge_index=ei, ptr=ptr, m=rng.choice([1, 2, 7, 33, 100]), k=rng.randint(1, 8),
+                          mode=rng.choice(["sample", "graph", "global"]), seed=rng.choice([42, 0, -5, 99991, 2**31 - 1, -2**31])))
+    _same(calls, product, orc, "random batches")
+
+
+@pytest.mark.parametrize("tier", ["0", "1", "2"])
+def test_every_walk_tier_gives_the_same_rows(tier, product, orc, monkeypatch):
+    """UGS_FORCE_TIER pins the first walk tier (8 lanes/walk cap 64; 64 lanes cap 512; 64 lanes cap 2048); graphs whose
+    candidate sets outgrow the tier are handed to the next one -- the rows must not depend on any of that."""
+    monkeypatch.setenv("UGS_FORCE_TIER", tier)
+    rng = random.Random(7 + int(tier))
+    calls = []
+    for n, p, k, m in [(30, 0.2, 5, 64), (120, 0.3, 6, 80), (300, 0.5, 5, 40), (700, 0.45, 4, 24)]:
+        e = [(u, v) for u in range(n) for v in range(u + 1, n) if rng.random() < p]
+        ei = np.array(e, dtype=np.int64).T.reshape(2, -1)
+        calls.append(dict(fn="sample_batch", edge_index=ei, ptr=np.array([0, n], dtype=np.int64), m=m, k=k, mode="graph", seed=11))
+    _same(calls, product, orc, f"tier {tier}")
+
+
+def test_hub_graph_uses_global_memory_tier(product, orc):
+    """a hub with 6000 neighbours: candidate sets of thousands of vertices (bucket chain past 2357 / 5087) exceed every
+    LDS tier and run in the global-memory workspace tier."""
+    rng = random.Random(5)
+    n = 6500
+    e = [(0, v) for v in range(1, 6001)] + [(rng.randrange(1, n), rng.randrange(1, n)) for _ in range(9000)]
+    e = [(u, v) for u, v in e if u != v]
+    ei = np.array(e, dtype=np.int64).T.reshape(2, -1)
+    calls = [dict(fn="sample_batch", edge_index=ei, ptr=np.array([0, n], dtype=np.int64), m=24, k=4, mode="sample", seed=42)]
+    _same(calls, product, orc, "hub graph")
+
+
+def test_handle_api_vs_oracle(product, orc):
+    rng = random.Random(2)
+    calls = []
+    for slot in range(12):
+        n = rng.choice([4, 9, 25, 60])
+        e = [(u, v) for u in range(n) for v in range(u + 1, n) if rng.random() < rng.choice([0.1, 0.4])]
+        if rng.random() < 0.5:
+            e = e + [(v, u) for u, v in e]
+        ei = np.array(e, dtype=np.int64).T.reshape(2, -1)
+        k = rng.randint(1, 7)
+        calls.append(dict(fn="create_preproc", edge_index=ei, num_nodes=n, k=k, slot=slot))
+        for em in ("local", "flat", "global"):
+            calls.append(dict(fn="sample", slot=slot, m=rng.choice([1, 17, 60]), k=rng.choice([k, max(1, k - 1)]), edge_mode=em,
+                              base_offset=rng.choice([0, 1000]), seed=rng.choice([42, -1, 0])))
+        calls.append(dict(fn="destroy_preproc", slot=slot))
+    _same(calls, product, orc, "handle API")
+
+
+def test_reference_pytest_assertions_on_gpu_output():
+    """the two real pytest tests of the reference (tests/test_sample_batch.py:18-41), on GPU output."""
+    import torch
+    import ugs_sampler
+    ptr = torch.tensor([0, 4, 8], dtype=torch.long)
+    edge_index = torch.tensor([[0, 1, 2, 4, 5, 6, 4], [1, 2, 3, 5, 6, 7, 7]], dtype=torch.long)
+    nodes_t, edge_index_t, edge_ptr_t, sample_ptr_t, edge_src = ugs_sampler.sample_batch(edge_index, ptr, 2, 3, mode="global")
+    for i, (u, v) in enumerate(edge_index_t.t().tolist()):
+        iu, iv = edge_index.t()[edge_src[i]].tolist()
+        assert (u, v) == (iu, iv) or (u, v) == (iv, iu)
+    nodes_t, edge_index_t, edge_ptr_t, sample_ptr_t, edge_src = ugs_sampler.sample_batch(edge_index, ptr, 2, 3, mode="sample")
+    ep = edge_ptr_t.tolist()
+    for i, (u, v) in enumerate(edge_index_t.t().tolist()):
+        g_id = next(j for j in range(len(ep) - 1) if ep[j] <= i < ep[j + 1])
+        ug, vg = nodes_t[g_id, u].item(), nodes_t[g_id, v].item()
+        iu, iv = edge_index.t()[edge_src[i]].tolist()
+        assert (ug, vg) == (iu, iv) or (ug, vg) == (iv, iu)
+    assert sample_ptr_t.tolist() == [0, 2, 4] and nodes_t.dtype == torch.int64 and nodes_t.shape == (4, 3)
+
+
+def test_uniformity_script_statistics_on_gpu_output():
+    """reference tests/test_uniformity.py (synthetic 6-ring, k=4, 5000 samples, seed 42) prints: 7 'unique',
+    counts 1492/1040/517/510/485/479/477, CV 0.517, POOR.  Identical numbers must come out of the GPU sampler."""
+    import json
+    import torch
+    import ugs_sampler
+    from uniformity_stats import script_stats
+    ei = torch.tensor([[0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 0], [1, 0, 2, 1, 3, 2, 4, 3, 5, 4, 0, 5]], dtype=torch.long)
+    ugs_sampler.clear_cache()
+    nodes, edge_index, edge_ptr, _, _ = ugs_sampler.sample_batch(ei, torch.tensor([0, 6]), m_per_graph=5000, k=4, mode="sample")
+    st = script_stats(nodes.numpy(), edge_index.numpy(), edge_ptr.numpy(), 4)
+    with open(os.path.join(sc.GOLDEN_DIR, "f3_ring_uniformity_stats.json")) as f:
+        assert st == json.load(f)["script"]
+    assert st["counts"] == [1492, 1040, 517, 510, 485, 479, 477] and st["cv"] == 0.517 and st["verdict"] == "POOR"
+
+
+def test_device_outputs_and_plan_row_ranges():
+    """device= returns the same values on the GPU; Plan.sample_rows over disjoint row ranges concatenates to the
+    full result (the basis of multi-GPU sharding)."""
+    import torch
+    import ugs_sampler
+    import ugs_workloads as wl
+    ei, ptr = wl.tu_batch(39, 73, 6)
+    ei_t, ptr_t = torch.from_numpy(ei), torch.from_numpy(ptr)
+    ugs_sampler.clear_cache()
+    m, k = 50, 6
+    for mode in ("sample", "graph", "global"):
+        host = ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode=mode, seed=9)
+        dev = ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode=mode, seed=9, device="cuda:0")
+        assert all(t.is_cuda for t in dev)
+        for a, b in zip(host, dev):
+            assert torch.equal(a, b.cpu())
+        plan = ugs_sampler.Plan.from_batch(ei_t, ptr_t, k)
+        rows = 6 * m
+        cuts = [0, 1, 77, 150, 151, rows]
+        parts = [plan.sample_rows(m, mode=mode, seed=9, row_begin=a, row_count=b - a) for a, b in zip(cuts[:-1], cuts[1:])]
+        nodes = torch.cat([p[0] for p in parts]).cpu()
+        eidx = torch.cat([p[1] for p in parts], dim=1).cpu()
+        esrc = torch.cat([p[3] for p in parts]).cpu()
+        counts = torch.cat([p[2][1:] - p[2][:-1] for p in parts]).cpu()
+        eptr = torch.cat([torch.zeros(1, dtype=torch.int64), counts.cumsum(0)])
+        assert torch.equal(nodes, host[0]) and torch.equal(eidx, host[1]) and torch.equal(eptr, host[2]) and torch.equal(esrc, host[4])
+        plan.close()
+
+
+def test_error_behaviour_matches_reference():
+    import torch
+    import ugs_sampler
+    ei = torch.tensor([[0, 1], [1, 2]], dtype=torch.long)
+    ptr = torch.tensor([0, 3], dtype=torch.long)
+    with pytest.raises(RuntimeError, match="mode must be one of: 'sample', 'graph', 'global'"):
+        ugs_sampler.sample_batch(ei, ptr, 1, 2, mode="nope")
+    with pytest.raises(RuntimeError, match="edge_index must be int64"):
+        ugs_sampler.sample_batch(ei.to(torch.int32), ptr, 1, 2)
+    with pytest.raises(RuntimeError, match="ptr must be int64"):
+        ugs_sampler.sample_batch(ei, ptr.to(torch.int32), 1, 2)
+    with pytest.raises(RuntimeError, match="edge_index must be on CPU"):
+        ugs_sampler.sample_batch(ei.cuda(), ptr, 1, 2)
+    with pytest.raises(RuntimeError, match="Invalid preproc handle"):
+        ugs_sampler.sample(987654321, 1, 2)
+    h = ugs_sampler.create_preproc(torch.zeros((2, 0), dtype=torch.long), 0, 2)
+    with pytest.raises(RuntimeError, match="No viable roots available"):
+        ugs_sampler.sample(h, 1, 2)
+    with pytest.raises(TypeError):
+        ugs_sampler.sample_batch(ei, ptr, 1, 2, seed=2**31)
+    # keyword call form used by the reference's tools (tools/graphlet_analysis.py:217-224)
+    out = ugs_sampler.sample_batch(edge_index=ei, ptr=ptr, m_per_graph=3, k=2, mode="sample", seed=1)
+    assert len(out) == 5 and out[0].shape == (3, 2) and out[0].is_pinned()
