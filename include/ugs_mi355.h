@@ -124,6 +124,12 @@ int ugs_plan_fill(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
 int ugs_plan_last_launch(const ugs_plan *plan, char *name_buf, int name_buf_len, int *grid, int *block,
                          int *lds_bytes, int64_t *overflow_rows);
 
+/* Per-kernel timing with HIP events recorded on the launch stream (off by default).  get_timing synchronises the
+ * recorded events, returns summed milliseconds and launch counts for [0] the first-tier walk kernel, [1] overflow
+ * tiers + scan kernels, [2] the fill kernel since the last call, and clears them. */
+int ugs_plan_set_timing(ugs_plan *plan, int on);
+int ugs_plan_get_timing(ugs_plan *plan, double *ms_sum3, int64_t *launches3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -373,8 +373,13 @@ struct ugs_plan {
     int64_t gws_groups = 0, gws_words = 0;
     int gcap = 0, ghs = 0, gbcap = 0, gpcap = 0;
     UgsLaunchInfo last_walk{nullptr, 0, 0, 0};
+    UgsLaunchInfo last_fill{nullptr, 0, 0, 0};
     int64_t last_overflow = 0;
     bool handle_api = false;
+    // optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline figure)
+    bool timing = false;
+    struct EvPair { hipEvent_t a, b; int kind; };     // kind 0 = first-tier walk kernel, 1 = overflow tiers + scan, 2 = fill kernel
+    std::vector<EvPair> events;
 };
 
 namespace {
@@ -451,8 +456,27 @@ int assemble_plan(const std::vector<PlanPiece> &pieces, const DeviceCtx &dc, ugs
     return UGS_OK;
 }
 
+hipError_t ev_begin(ugs_plan *p, int kind, hipStream_t s) {
+    if (!p->timing) return hipSuccess;
+    ugs_plan::EvPair e{nullptr, nullptr, kind};
+    hipError_t r = hipEventCreate(&e.a);
+    if (r == hipSuccess) r = hipEventCreate(&e.b);
+    if (r == hipSuccess) r = hipEventRecord(e.a, s);
+    p->events.push_back(e);
+    return r;
+}
+hipError_t ev_end(ugs_plan *p, hipStream_t s) {
+    if (!p->timing || p->events.empty()) return hipSuccess;
+    return hipEventRecord(p->events.back().b, s);
+}
+void ev_clear(ugs_plan *p) {
+    for (auto &e : p->events) { if (e.a) (void)hipEventDestroy(e.a); if (e.b) (void)hipEventDestroy(e.b); }
+    p->events.clear();
+}
+
 void destroy_plan(ugs_plan *p) {
     if (!p) return;
+    ev_clear(p);
     if (p->blob) (void)hipFree(p->blob);
     pool_put(p->counts); pool_put(p->ovf1); pool_put(p->ovf2); pool_put(p->ovfcnt); pool_put(p->scantmp);
     if (p->gws.p) { (void)hipFree(p->gws.p); p->gws = PoolBuf(); }
@@ -781,7 +805,10 @@ int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
     a.in_list = nullptr; a.in_count = nullptr;
     a.ovf_list = static_cast<int64_t *>(plan->ovf1.p);
     a.ovf_count = cnt + 0;
+    HIP_TRY(ev_begin(plan, 0, s));
     HIP_TRY(ugs_launch_walk(a, tc.first, plan->cus, s, &plan->last_walk));
+    HIP_TRY(ev_end(plan, s));
+    HIP_TRY(ev_begin(plan, 1, s));
     int last = 0;   // index of the counter holding rows that nobody processed
     if (tc.second_L) {
         a.in_list = static_cast<const int64_t *>(plan->ovf1.p); a.in_count = cnt + 0;
@@ -816,6 +843,7 @@ int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
         last = 2;
     }
     HIP_TRY(ugs_launch_scan(static_cast<const uint32_t *>(plan->counts.p), row_count, d_edge_ptr, static_cast<int64_t *>(plan->scantmp.p), s));
+    HIP_TRY(ev_end(plan, s));
     if (total_edges_host) {
         uint32_t h[4] = {0, 0, 0, 0};
         int64_t tot = 0;
@@ -847,7 +875,33 @@ int ugs_plan_fill(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
     a.nodes = d_nodes; a.edge_ptr = d_edge_ptr;
     a.edge_index = d_edge_index; a.ld = ld; a.edge_src = d_edge_src;
     const TierChoice tc = choose_tier(plan, k);
-    HIP_TRY(ugs_launch_fill(a, tc.first != UGS_TIER_S, plan->cus, static_cast<hipStream_t>(stream), nullptr));
+    std::lock_guard<std::mutex> lk(plan->mu);
+    HIP_TRY(ev_begin(plan, 2, static_cast<hipStream_t>(stream)));
+    HIP_TRY(ugs_launch_fill(a, tc.first != UGS_TIER_S, plan->cus, static_cast<hipStream_t>(stream), &plan->last_fill));
+    HIP_TRY(ev_end(plan, static_cast<hipStream_t>(stream)));
+    return UGS_OK;
+}
+
+int ugs_plan_set_timing(ugs_plan *plan, int on) {
+    if (!plan) return fail(UGS_E_BAD_ARG, "plan is null");
+    std::lock_guard<std::mutex> lk(plan->mu);
+    ev_clear(plan);
+    plan->timing = on != 0;
+    return UGS_OK;
+}
+
+int ugs_plan_get_timing(ugs_plan *plan, double *ms_sum3, int64_t *launches3) {
+    if (!plan || !ms_sum3 || !launches3) return fail(UGS_E_BAD_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(plan->mu);
+    for (int i = 0; i < 3; ++i) { ms_sum3[i] = 0.0; launches3[i] = 0; }
+    for (auto &e : plan->events) {
+        HIP_TRY(hipEventSynchronize(e.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
+        ms_sum3[e.kind] += (double)ms;
+        launches3[e.kind] += 1;
+    }
+    ev_clear(plan);
     return UGS_OK;
 }
 

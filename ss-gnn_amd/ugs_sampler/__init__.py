@@ -250,6 +250,15 @@ class Plan:
         check(lib.ugs_plan_last_launch(self._h, name, 128, C.byref(grid), C.byref(block), C.byref(lds), C.byref(ovf)))
         return {"kernel": name.value.decode(), "grid": grid.value, "block": block.value, "lds_bytes": lds.value, "overflow_rows": ovf.value}
 
+    def set_timing(self, on=True):
+        check(lib.ugs_plan_set_timing(self._h, 1 if on else 0))
+
+    def get_timing(self):
+        """{"walk": (ms, launches), "scan": (...), "fill": (...)} since the last call (HIP events on the launch stream)."""
+        ms, n = (C.c_double * 3)(), (C.c_int64 * 3)()
+        check(lib.ugs_plan_get_timing(self._h, ms, n))
+        return {name: (ms[i], n[i]) for i, name in enumerate(("walk", "scan", "fill"))}
+
     def walk(self, m_per_graph, mode="sample", seed=42, row_begin=0, row_count=None, extra_node_offset=0, out=None, sync=True):
         """Walk phase: returns (nodes [rows,k], edge_ptr [rows+1], total_edges or None) as device tensors."""
         m, seed = _as_c_int(m_per_graph, "m_per_graph"), _as_c_int(seed, "seed")

@@ -1,0 +1,85 @@
+"""CPU, multi-process (gloo): the N>1 path -- row sharding + collation of ugs_sampler.distributed -- with the CPU oracle
+standing in for the per-rank row sampler (the oracle is the checker here; the shipped default row sampler is the HIP plan
+path).  The collated batch on every rank must equal the single-process result bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, all_ranks, q):
+    for p in (os.path.join(ROOT, "ss-gnn_amd"), os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, p)
+    import oracle
+    import ugs_workloads as wl
+    from ugs_sampler import distributed as ud
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        ei, ptr = wl.tu_batch(18, 20, 5)
+        ei = np.concatenate([ei, np.array([[3], [40]], dtype=np.int64)], axis=1)      # a cross-graph column
+        m, k, seed = 7, 4, 42
+        full = oracle.sample_batch(ei, ptr, m, k, mode, seed)
+
+        def row_sampler(m_, mode_, seed_, begin, count):      # stand-in: rows [begin, begin+count) of the full result
+            nodes, eidx, eptr, _, esrc = full
+            e0, e1 = int(eptr[begin]), int(eptr[begin + count])
+            pad = np.full((2, 5), -7, dtype=np.int64)          # capacity slack beyond `total`, must be ignored
+            return (torch.from_numpy(nodes[begin:begin + count].copy()),
+                    torch.from_numpy(np.concatenate([eidx[:, e0:e1], pad], axis=1)),
+                    torch.from_numpy((eptr[begin:begin + count + 1] - e0).copy()),
+                    torch.from_numpy(np.concatenate([esrc[e0:e1], pad[0]])))
+
+        res = ud.sample_batch_sharded(torch.from_numpy(ei), torch.from_numpy(ptr), m, k, mode=mode, seed=seed,
+                                      all_ranks=all_ranks, dst=0, row_sampler=row_sampler)
+        if res is None:
+            ok = (not all_ranks) and rank != 0
+        else:
+            ok = all(np.array_equal(a.numpy(), b) and a.dtype == torch.int64 for a, b in zip(res, full))
+        begin, count = ud.shard_range(5 * m, rank, world)
+        q.put((rank, bool(ok), begin, count))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode,all_ranks", [(2, "sample", True), (2, "global", False), (3, "graph", True)])
+def test_sharded_collation_equals_single_process(world, mode, all_ranks):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, all_ranks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert all(ok for _, ok, _, _ in got)
+    assert [b for _, _, b, _ in got] == [sum(c for _, _, _, c in got[:i]) for i in range(world)]     # contiguous cover
+    assert sum(c for _, _, _, c in got) == 5 * 7
+
+
+def test_shard_range_properties():
+    for p in (os.path.join(ROOT, "ss-gnn_amd"),):
+        sys.path.insert(0, p)
+    from ugs_sampler.distributed import shard_range
+    for total in (0, 1, 7, 8, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+            assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1

@@ -207,3 +207,28 @@ def test_error_behaviour_matches_reference():
     # keyword call form used by the reference's tools (tools/graphlet_analysis.py:217-224)
     out = ugs_sampler.sample_batch(edge_index=ei, ptr=ptr, m_per_graph=3, k=2, mode="sample", seed=1)
     assert len(out) == 5 and out[0].shape == (3, 2) and out[0].is_pinned()
+
+
+def test_sharded_path_over_rccl_single_rank():
+    """the shipped default row sampler (HIP plan) + the collation over the nccl(=RCCL) backend, world size 1 on the
+    one GPU of the box (the multi-rank collation logic itself is covered over gloo on the CPU)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    import ugs_sampler
+    import ugs_workloads as wl
+    from ugs_sampler import distributed as ud
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ei, ptr = wl.tu_batch(18, 19, 6)
+        ei_t, ptr_t = torch.from_numpy(ei), torch.from_numpy(ptr)
+        ugs_sampler.clear_cache()
+        for mode, all_ranks in (("sample", True), ("graph", False), ("global", True)):
+            want = ugs_sampler.sample_batch(ei_t, ptr_t, 40, 5, mode=mode, seed=3)
+            got = ud.sample_batch_sharded(ei_t, ptr_t, 40, 5, mode=mode, seed=3, all_ranks=all_ranks)
+            for a, b in zip(got, want):
+                assert a.is_cuda and torch.equal(a.cpu(), b)
+    finally:
+        dist.destroy_process_group()
