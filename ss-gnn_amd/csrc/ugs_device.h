@@ -72,7 +72,7 @@ struct UgsWalkArgs {
     int32_t gcap;            // candidate capacity of the global tier
     int32_t ghs;             // hash slots (power of two) of the global tier
     int32_t gbcap;           // bucket-table entries of the global tier
-    int32_t gpcap;           // ordered-prefix capacity of the global tier
+    int32_t gpcap;           // words of all materialised stage orders of the global tier
 };
 
 struct UgsFillArgs {
@@ -104,3 +104,4 @@ int64_t ugs_scan_tmp_words(int64_t rows);
 int64_t ugs_global_ws_words(int64_t gcap, int64_t gbcap, int64_t gpcap, int64_t ghs);
 uint32_t ugs_chain_at_least(int64_t c, int *index_out);
 uint32_t ugs_chain_value(int idx);
+int64_t ugs_ord_words(int stages);

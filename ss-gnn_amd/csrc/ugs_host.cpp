@@ -822,7 +822,7 @@ int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
             const int64_t gcap = std::max<int64_t>(tc.bound, 1);
             const uint32_t gb = ugs_chain_at_least(gcap, &idx);
             if (!gb) return fail(UGS_E_UNSUPPORTED, "candidate-set bound too large");
-            const int64_t prev = idx > 0 ? (int64_t)ugs_chain_value(idx - 1) : 1;   // longest ordered prefix ever materialised
+            const int64_t prev = std::max<int64_t>(ugs_ord_words(idx), 4);            // orders of every stage below the last one
             int64_t hs = 128;
             while (hs < 2 * (gcap + 65 + 1)) hs <<= 1;
             const int64_t words = ugs_global_ws_words(gcap, gb, prev, hs);

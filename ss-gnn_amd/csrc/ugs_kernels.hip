@@ -27,6 +27,8 @@
 //   * ballot + popcount prefix sums compact new candidates into D and (fill kernel) edges into the output.
 #include "ugs_device.h"
 
+#define UGS_ALIGNED16 __attribute__((aligned(16)))
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -42,10 +44,20 @@ constexpr uint32_t kChainHost[kChainLen] = {13u, 29u, 59u, 127u, 257u, 541u, 110
 constexpr int clog2(uint32_t b) { int s = 0; while ((1ull << s) < b) ++s; return s; }
 constexpr uint32_t cmagic(uint32_t b) { return (uint32_t)(((1ull << (31 + clog2(b))) / b) + 1ull); }
 
-struct ChainTab { uint32_t B[kChainLen]; uint32_t M[kChainLen]; uint32_t S[kChainLen]; };
+// O[i] = word offset of stage i's materialised order (every stage keeps its own array so that the orders of the leading
+// stages survive from one growth step to the next; sizes padded to even)
+struct ChainTab { uint32_t B[kChainLen]; uint32_t M[kChainLen]; uint32_t S[kChainLen]; uint32_t O[kChainLen]; };
+constexpr uint32_t ord_words_before(int stage) {
+    unsigned long long o = 0;
+    for (int i = 0; i < stage && i < kChainLen; ++i) o += (kChainHost[i] + 1u) & ~1u;
+    return o > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)o;
+}
 constexpr ChainTab make_chain() {
     ChainTab t{};
-    for (int i = 0; i < kChainLen; ++i) { t.B[i] = kChainHost[i]; t.M[i] = cmagic(kChainHost[i]); t.S[i] = (uint32_t)clog2(kChainHost[i]) - 1u; }
+    for (int i = 0; i < kChainLen; ++i) {
+        t.B[i] = kChainHost[i]; t.M[i] = cmagic(kChainHost[i]); t.S[i] = (uint32_t)clog2(kChainHost[i]) - 1u;
+        t.O[i] = ord_words_before(i);
+    }
     return t;
 }
 __constant__ ChainTab d_chain = make_chain();
@@ -86,6 +98,29 @@ template <int GS> struct Grp {
     __device__ __forceinline__ bool any(bool p) const { return ballot(p) != 0ull; }
     __device__ __forceinline__ uint64_t lt_mask() const { return (1ull << lane) - 1ull; }
     template <class T> __device__ __forceinline__ T bcast(T v, int src) const { return __shfl(v, gbase + src, 64); }
+    // inclusive prefix sum over the group's lanes (sum of x over lanes <= lane).  GS == 64: the whole wave is active
+    // here, so the DPP row-shift / row-broadcast scan is used (6 VALU ops, no LDS crossbar traffic).
+    __device__ __forceinline__ uint32_t prefix_incl(uint32_t x) const {
+        if (GS == 64) {
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+            return x;
+        }
+#pragma unroll
+        for (int d = 1; d < GS; d <<= 1) {
+            uint32_t y = __shfl_up(x, d, GS);
+            if (lane >= d) x += y;
+        }
+        return x;
+    }
+    __device__ __forceinline__ uint32_t last(uint32_t incl) const {      // value held by the group's last lane
+        if (GS == 64) return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        return bcast(incl, GS - 1);
+    }
     // inclusive suffix sum over the group's lanes: sum of x over lanes >= lane
     __device__ __forceinline__ uint32_t suffix_incl(uint32_t x) const {
 #pragma unroll
@@ -115,8 +150,8 @@ struct GlbSpace {       // global-memory fallback: agent-scope fence between pha
 
 template <class SP> struct Work {
     uint32_t *D;             // distinct candidates, first-insertion order           [cap]
-    uint32_t *SA, *SB;       // ordered prefixes (ping-pong)                         [pcap]
-    typename SP::TA *AUX;    // per element: position inside its bucket              [cap]
+    uint32_t *ORD;           // materialised order of every non-final stage, stage i at ORD + d_chain.O[i]
+    typename SP::TA *AUX;    // per element: position inside its bucket (generic path only)   [cap]
     typename SP::TW *TBL;    // per bucket: (round|pos) -> (size|first) -> start     [bcap]
     uint32_t *HK, *HP;       // membership hash: key / (local index in sample | first-seen sequence number)  [hs]
     uint32_t cap, hmask, hlimit;
@@ -129,15 +164,18 @@ __device__ __forceinline__ uint32_t hash_slot(uint32_t w, uint32_t mask) { retur
 // iteration-order selection: vertex at position `rsel` of the libstdc++ unordered_set<int> built by inserting
 // D[0..c) one by one (see file header).  c >= 1, rsel < c.  Group-uniform result.
 template <int GS, class SP>
-__device__ __forceinline__ uint32_t select_in_order(const Work<SP> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel) {
+__device__ __forceinline__ uint32_t select_in_order(const Work<SP> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel, int &nvalid) {
     using TW = typename SP::TW;
     using TA = typename SP::TA;
-    uint32_t *OLD = ws.SA, *NEW = ws.SB;
-    uint32_t n_old = 0;
-    for (int stage = 0; stage < kChainLen; ++stage) {     // terminates at the first chain value >= c
+    int fs = 0;
+    while (fs < kChainLen - 1 && d_chain.B[fs] < c) ++fs;                // the final stage: first chain value >= c
+    for (int stage = nvalid < fs ? nvalid : fs; stage < kChainLen; ++stage) {
         const uint32_t B = d_chain.B[stage], M = d_chain.M[stage], S = d_chain.S[stage];
         const uint32_t L = c < B ? c : B;
-        const bool final = c <= B;
+        const bool final = stage == fs;
+        const uint32_t *OLD = stage ? ws.ORD + d_chain.O[stage - 1] : ws.D;
+        uint32_t *NEW = ws.ORD + d_chain.O[stage];
+        const uint32_t n_old = stage ? d_chain.B[stage - 1] : 0u;
         for (uint32_t b = g.lane; b < B; b += GS) ws.TBL[b] = 0;
         for (uint32_t t = g.lane; t < L; t += GS) ws.AUX[t] = SP::UNASSIGNED;
         SP::sync();
@@ -202,10 +240,122 @@ __device__ __forceinline__ uint32_t select_in_order(const Work<SP> &ws, const Gr
             int src = mk ? (__ffsll((long long)mk) - 1) : 0;
             return g.bcast(mine, src);
         }
-        uint32_t *tmp = OLD; OLD = NEW; NEW = tmp;
-        n_old = L;
+        nvalid = stage + 1;
     }
     return ws.D[0];   // unreachable for c within the chain
+}
+
+// One stage of the order computation with every element held in REGISTERS: lane l owns the NJ consecutive positions
+// [l*NJ, l*NJ + NJ) (NJ odd -> the lane stride is conflict-free on the 32 LDS banks), LDS operations of a phase are
+// issued back to back and waited for once, the bucket starts come from per-lane running sums plus ONE group-wide scan.
+template <int GS, int NJ>
+__device__ __forceinline__ void stage_fast(const Work<LdsSpace> &ws, const Grp<GS> &g, const uint32_t *OLD, uint32_t *NEW,
+                                           uint32_t n_old, uint32_t L, uint32_t B, uint32_t M, uint32_t S, bool final,
+                                           uint32_t rsel, bool &have, uint32_t &mine) {
+    const uint32_t t0 = (uint32_t)g.lane * NJ;
+    uint32_t key[NJ], bk[NJ], rho[NJ];
+    {   // clear the bucket table with 16-byte stores
+        uint4 *T4 = reinterpret_cast<uint4 *>(ws.TBL);
+        const uint32_t n4 = (B + 3u) >> 2;
+        for (uint32_t i = g.lane; i < n4; i += GS) T4[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const uint32_t t = t0 + j;
+        key[j] = 0u;
+        if (t < L) key[j] = (t < n_old) ? OLD[t] : ws.D[t];
+    }
+    LdsSpace::sync();
+    uint64_t un = 0ull;     // bit j: own element j not placed yet (NJ can be 33)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        bk[j] = mod_magic(key[j], B, M, S);
+        rho[j] = 0u;
+        if (t0 + j < L) un |= 1ull << j;
+    }
+    // peel rounds: the still-unplaced element with the largest position wins its bucket in every round
+    for (uint32_t round = 1; round <= L; ++round) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if ((un >> j) & 1ull) atomicMax(&ws.TBL[bk[j]], (round << 16) | (t0 + j));
+        LdsSpace::sync();
+        uint32_t v[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) v[j] = ((un >> j) & 1ull) ? ws.TBL[bk[j]] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (((un >> j) & 1ull) && (v[j] & 0xFFFFu) == t0 + j) { rho[j] = round - 1u; un &= ~(1ull << j); }
+        LdsSpace::sync();
+        if (!g.any(un != 0ull)) break;
+    }
+    // bucket entry = (size << 16) | first position.  Buckets are laid out by DESCENDING first position.
+    uint32_t gs[NJ], mine_total = 0u;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) gs[j] = (t0 + j < L) ? ws.TBL[bk[j]] : 0u;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        gs[j] = ((t0 + j < L) && (gs[j] & 0xFFFFu) == t0 + j) ? (gs[j] >> 16) : 0u;    // size if this element leads its bucket
+        mine_total += gs[j];
+    }
+    const uint32_t incl = g.prefix_incl(mine_total);
+    uint32_t run = g.last(incl) - incl;          // elements of buckets led from higher lanes
+    LdsSpace::sync();                             // every lane has read the sizes before leaders overwrite them
+#pragma unroll
+    for (int j = NJ - 1; j >= 0; --j) {
+        if (gs[j]) ws.TBL[bk[j]] = run;           // bucket start rank
+        run += gs[j];
+    }
+    LdsSpace::sync();
+    uint32_t st[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) st[j] = (t0 + j < L) ? ws.TBL[bk[j]] : 0u;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (t0 + j < L) {
+            const uint32_t rank = st[j] + rho[j];
+            if (final) { if (rank == rsel) { have = true; mine = key[j]; } }
+            else NEW[rank] = key[j];
+        }
+    }
+    LdsSpace::sync();
+}
+
+// LDS tiers: iteration-order selection with the register-resident stages; `nvalid` = number of leading stages whose
+// materialised order is still valid (the candidates they cover did not change since they were computed).
+template <int GS, int MAXPER>
+__device__ __forceinline__ uint32_t select_lds(const Work<LdsSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel, int &nvalid) {
+    int fs = 0;
+    while (fs < kChainLen - 1 && d_chain.B[fs] < c) ++fs;
+    bool have = false;
+    uint32_t mine = 0u;
+    for (int stage = nvalid < fs ? nvalid : fs; stage <= fs; ++stage) {
+        const uint32_t B = d_chain.B[stage], M = d_chain.M[stage], S = d_chain.S[stage];
+        const uint32_t L = c < B ? c : B;
+        const bool final = stage == fs;
+        const uint32_t *OLD = stage ? ws.ORD + d_chain.O[stage - 1] : ws.D;
+        uint32_t *NEW = ws.ORD + d_chain.O[stage];
+        const uint32_t n_old = stage ? d_chain.B[stage - 1] : 0u;
+        const uint32_t per = (L + GS - 1) / GS;
+        if (per <= 1) stage_fast<GS, 1>(ws, g, OLD, NEW, n_old, L, B, M, S, final, rsel, have, mine);
+        else if (per <= 3) stage_fast<GS, 3>(ws, g, OLD, NEW, n_old, L, B, M, S, final, rsel, have, mine);
+        else if (per <= 5) stage_fast<GS, 5>(ws, g, OLD, NEW, n_old, L, B, M, S, final, rsel, have, mine);
+        else if (per <= 9 || MAXPER <= 9) stage_fast<GS, 9>(ws, g, OLD, NEW, n_old, L, B, M, S, final, rsel, have, mine);
+        else if constexpr (MAXPER > 9) {
+            if (per <= 17) stage_fast<GS, 17>(ws, g, OLD, NEW, n_old, L, B, M, S, final, rsel, have, mine);
+            else stage_fast<GS, 33>(ws, g, OLD, NEW, n_old, L, B, M, S, final, rsel, have, mine);
+        }
+        if (!final) nvalid = stage + 1;
+    }
+    const uint64_t mk = g.ballot(have);
+    const int src = mk ? (__ffsll((long long)mk) - 1) : 0;
+    return g.bcast(mine, src);
+}
+
+template <int GS, int MAXPER> __device__ __forceinline__ uint32_t select_any(const Work<LdsSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel, int &nvalid) {
+    return select_lds<GS, MAXPER>(ws, g, c, rsel, nvalid);
+}
+template <int GS, int MAXPER> __device__ __forceinline__ uint32_t select_any(const Work<GlbSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel, int &nvalid) {
+    return select_in_order<GS, GlbSpace>(ws, g, c, rsel, nvalid);
 }
 
 // Adjacency row of the vertex just added to the sample (local index size-1):
@@ -270,7 +420,7 @@ __device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, c
 }
 
 // One walk.  Returns false on workspace overflow (the row is then redone by the next tier).
-template <int GS, class SP>
+template <int GS, class SP, int MAXPER>
 __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, const UgsWalkArgs &a, int64_t row_rel,
                                         uint32_t *SV /* [UGS_KMAX] group-private */) {
     const UgsPlanDev &P = a.plan;
@@ -302,32 +452,49 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
         root_vi = (uint32_t)vr.x;
         root_v = (uint32_t)vr.y;
     }
-    // reset the membership hash
-    for (uint32_t s = g.lane; s <= ws.hmask; s += GS) { ws.HK[s] = kEmpty; ws.HP[s] = kEmpty; }
+    // reset the membership hash (HK and HP are adjacent: 2 * slots words of 0xFFFFFFFF, 16 bytes per store)
+    {
+        uint4 *H4 = reinterpret_cast<uint4 *>(ws.HK);
+        const uint32_t n4 = (ws.hmask + 1u) >> 1;
+        for (uint32_t s = g.lane; s < n4; s += GS) H4[s] = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
+    }
     SP::sync();
     if (g.lane == 0) { uint32_t s = hash_slot(root_v, ws.hmask); ws.HK[s] = root_v; ws.HP[s] = 0; SV[0] = root_v; }
     SP::sync();
     uint32_t size = 1, c = 0, hcount = 1, seq = UGS_KMAX, ecount = 0;
+    int nvalid = 0;           // leading stages of the order computation that are still valid
     bool ok = (k > 1) ? scan_row<GS, SP, true>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, seq, ecount)
                       : scan_row<GS, SP, false>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, seq, ecount);
     if (!ok) return false;
     for (int step = 1; step < k; ++step) {
         if (c == 0) break;                                                    // growth failed: partial row
         const uint32_t rsel = (uint32_t)(rng.next() % (uint64_t)c);
-        const uint32_t w = select_in_order<GS, SP>(ws, g, c, rsel);
+        const uint32_t w = select_any<GS, MAXPER>(ws, g, c, rsel, nvalid);
         // move w from the candidates to the sample: drop it from D keeping the order of the others
         uint32_t q = c;
-        for (uint32_t t0 = 0; t0 < c; t0 += GS) {
-            uint32_t t = t0 + g.lane;
-            uint64_t mk = g.ballot(t < c && ws.D[t] == w);
-            if (mk) { q = t0 + (uint32_t)(__ffsll((long long)mk) - 1); break; }
+        for (uint32_t t0 = 0; t0 < c && q == c; t0 += 4 * GS) {        // 4 chunks per LDS round trip
+            uint32_t x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t t = t0 + u * GS + g.lane; x[u] = (t < c) ? ws.D[t] : kEmpty; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint64_t mk = g.ballot(x[u] == w);
+                if (mk && q == c) q = t0 + u * GS + (uint32_t)(__ffsll((long long)mk) - 1);
+            }
         }
-        for (uint32_t t0 = q; t0 + 1 < c; t0 += GS) {
-            uint32_t t = t0 + g.lane;
-            uint32_t x = (t + 1 < c) ? ws.D[t + 1] : 0u;
+        for (uint32_t t0 = q; t0 + 1 < c; t0 += 4 * GS) {
+            uint32_t x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t t = t0 + u * GS + g.lane; x[u] = (t + 1 < c) ? ws.D[t + 1] : 0u; }
             SP::sync();
-            if (t + 1 < c) ws.D[t] = x;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t t = t0 + u * GS + g.lane; if (t + 1 < c) ws.D[t] = x[u]; }
             SP::sync();
+        }
+        {   // stages whose candidates all precede position q keep their order
+            int keep = 0;
+            while (keep < nvalid && d_chain.B[keep] <= q) ++keep;
+            nvalid = keep;
         }
         c -= 1;
         if (g.lane == 0) {
@@ -349,30 +516,30 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
     return true;
 }
 
-// LDS words of one group's workspace for a tier
+// LDS words of one group's workspace for a tier (all sub-arrays 16-byte aligned)
 template <int CAP> struct TierCfg {
-    static constexpr int PCAP = CAP <= 64 ? 59 : (CAP <= 512 ? 257 : 1109);      // largest chain value < CAP
-    static constexpr int BCAP = CAP <= 64 ? 127 : (CAP <= 512 ? 541 : 2357);     // smallest chain value >= CAP
+    static constexpr int NSTAGE = CAP <= 64 ? 3 : (CAP <= 512 ? 5 : 7);           // stages that are ever materialised
+    static constexpr int ORDW = (int)((ord_words_before(NSTAGE) + 3u) & ~3u);     // 104 / 492 / 2144 words
+    static constexpr int BCAP = CAP <= 64 ? 127 : (CAP <= 512 ? 541 : 2357);      // smallest chain value >= CAP
+    static constexpr int BCAP_A = (BCAP + 3) & ~3;
     static constexpr int HS = CAP <= 64 ? 128 : (CAP <= 512 ? 1024 : 4096);
-    static constexpr int PCAP_A = (PCAP + 1) & ~1, BCAP_A = (BCAP + 1) & ~1;
-    static constexpr int WORDS = CAP /*D*/ + 2 * PCAP_A /*SA,SB*/ + CAP / 2 /*AUX u16*/ + BCAP_A /*TBL*/ + 2 * HS /*HK,HP*/ + UGS_KMAX /*SV*/;
+    static constexpr int WORDS = CAP /*D*/ + ORDW + BCAP_A /*TBL*/ + 2 * HS /*HK,HP*/ + UGS_KMAX /*SV*/;
 };
 
 template <int GS, int CAP, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void ugs_walk_lds(UgsWalkArgs a) {
     using Cfg = TierCfg<CAP>;
     constexpr int GROUPS = BLOCK / GS;
-    __shared__ uint32_t lds[GROUPS * Cfg::WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[GROUPS * Cfg::WORDS];
     Grp<GS> g;
     g.init();
     const int gib = (int)threadIdx.x / GS;
     uint32_t *base = lds + gib * Cfg::WORDS;
     Work<LdsSpace> ws;
     ws.D = base;
-    ws.SA = ws.D + CAP;
-    ws.SB = ws.SA + Cfg::PCAP_A;
-    ws.AUX = (uint16_t *)(ws.SB + Cfg::PCAP_A);
-    ws.TBL = ws.SB + Cfg::PCAP_A + CAP / 2;
+    ws.ORD = ws.D + CAP;
+    ws.AUX = nullptr;                      // the register-resident stages need no per-element scratch
+    ws.TBL = ws.ORD + Cfg::ORDW;
     ws.HK = ws.TBL + Cfg::BCAP_A;
     ws.HP = ws.HK + Cfg::HS;
     uint32_t *SV = ws.HP + Cfg::HS;
@@ -383,7 +550,7 @@ __global__ __launch_bounds__(BLOCK) void ugs_walk_lds(UgsWalkArgs a) {
     const int64_t ngroups = (int64_t)gridDim.x * GROUPS;
     for (int64_t it = (int64_t)blockIdx.x * GROUPS + gib; it < total; it += ngroups) {
         const int64_t row_rel = a.in_list ? a.in_list[it] : it;
-        if (!do_walk<GS, LdsSpace>(ws, g, a, row_rel, SV)) {
+        if (!do_walk<GS, LdsSpace, (CAP + GS - 1) / GS>(ws, g, a, row_rel, SV)) {
             if (g.lane == 0) { uint32_t pos = atomicAdd(a.ovf_count, 1u); a.ovf_list[pos] = row_rel; }
         }
     }
@@ -396,13 +563,12 @@ __global__ __launch_bounds__(64) void ugs_walk_global(UgsWalkArgs a) {
     g.init();
     uint32_t *base = a.gws + (int64_t)blockIdx.x * a.gws_words_per_group;
     Work<GlbSpace> ws;
-    const int64_t pc = ((int64_t)a.gpcap + 1) & ~1ll;
-    ws.TBL = (unsigned long long *)base;                         // 8-byte aligned first
-    ws.D = base + 2 * (((int64_t)a.gbcap + 1) & ~1ll);
-    ws.SA = ws.D + (((int64_t)a.gcap + 1) & ~1ll);
-    ws.SB = ws.SA + pc;
-    ws.AUX = ws.SB + pc;
-    ws.HK = ws.AUX + (((int64_t)a.gcap + 1) & ~1ll);
+    auto al4 = [](int64_t x) { return (x + 3) & ~3ll; };
+    ws.TBL = (unsigned long long *)base;                         // 8-byte words first
+    ws.D = base + 2 * al4(a.gbcap);
+    ws.ORD = ws.D + al4(a.gcap);
+    ws.AUX = ws.ORD + al4(a.gpcap);                              // gpcap = words of all materialised stage orders
+    ws.HK = ws.AUX + al4(a.gcap);
     ws.HP = ws.HK + a.ghs;
     ws.cap = (uint32_t)a.gcap;
     ws.hmask = (uint32_t)a.ghs - 1u;
@@ -410,7 +576,7 @@ __global__ __launch_bounds__(64) void ugs_walk_global(UgsWalkArgs a) {
     const int64_t total = a.in_list ? (int64_t)*a.in_count : a.row_count;
     for (int64_t it = blockIdx.x; it < total; it += gridDim.x) {
         const int64_t row_rel = a.in_list ? a.in_list[it] : it;
-        if (!do_walk<64, GlbSpace>(ws, g, a, row_rel, SV)) {
+        if (!do_walk<64, GlbSpace, 0>(ws, g, a, row_rel, SV)) {
             // cannot happen when gcap covers the graph's bound; mark the row so the host can report it
             if (g.lane == 0) { uint32_t pos = atomicAdd(a.ovf_count, 1u); a.ovf_list[pos] = row_rel; }
         }
@@ -558,9 +724,11 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
 int64_t ugs_scan_tmp_words(int64_t rows) { return (rows + kScanTile - 1) / kScanTile + 1; }
 
 int64_t ugs_global_ws_words(int64_t gcap, int64_t gbcap, int64_t gpcap, int64_t ghs) {
-    auto ev = [](int64_t x) { return (x + 1) & ~1ll; };
-    return 2 * ev(gbcap) + ev(gcap) + 2 * ev(gpcap) + ev(gcap) + 2 * ghs;
+    auto al4 = [](int64_t x) { return (x + 3) & ~3ll; };
+    return 2 * al4(gbcap) + al4(gcap) + al4(gpcap) + al4(gcap) + 2 * ghs;
 }
+
+int64_t ugs_ord_words(int stages) { return (int64_t)ord_words_before(stages); }   // words holding the orders of stages [0, stages)
 
 uint32_t ugs_chain_value(int idx) { return (idx >= 0 && idx < kChainLen) ? kChainHost[idx] : 0u; }
 
@@ -587,7 +755,7 @@ hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, hipStream_t 
     if (cus <= 0) cus = 256;
     switch (tier) {
     case UGS_TIER_S: return launch_lds<8, 64, 256>(a, cus, 2, s, info, "ugs_walk_lds<8,64>");
-    case UGS_TIER_M: return launch_lds<64, 512, 64>(a, cus, 10, s, info, "ugs_walk_lds<64,512>");
+    case UGS_TIER_M: return launch_lds<64, 512, 64>(a, cus, 11, s, info, "ugs_walk_lds<64,512>");
     case UGS_TIER_L: return launch_lds<64, 2048, 64>(a, cus, 2, s, info, "ugs_walk_lds<64,2048>");
     default: {
         int64_t grid = a.gws_words_per_group > 0 ? a.gws_groups : 0;

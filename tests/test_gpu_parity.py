@@ -10,7 +10,7 @@ import pytest
 
 import scenarios as sc
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180)]
 
 
 @pytest.fixture(scope="module")
