@@ -29,6 +29,21 @@
 
 #define UGS_ALIGNED16 __attribute__((aligned(16)))
 
+// Diagnostic build only (-DUGS_STAMPS, never shipped): per-phase shader-cycle totals of the walk kernel, added by lane 0
+// of every group into a buffer of its own (ugs_stamp_buffer); no output value depends on them.
+#ifdef UGS_STAMPS
+__device__ unsigned long long ugs_stamp_buffer[16];
+#define STAMP_DECL unsigned long long st_t0 = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP_BEGIN() do { __builtin_amdgcn_sched_barrier(0); st_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_END(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t1_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); st_acc[i] += t1_ - st_t0; st_t0 = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_FLUSH(lane) do { if ((lane) == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&ugs_stamp_buffer[i_], st_acc[i_]); atomicAdd(&ugs_stamp_buffer[8], 1ull); } } while (0)
+#else
+#define STAMP_DECL
+#define STAMP_BEGIN() do {} while (0)
+#define STAMP_END(i) do {} while (0)
+#define STAMP_FLUSH(lane) do {} while (0)
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -266,27 +281,32 @@ __device__ __forceinline__ void stage_fast(const Work<LdsSpace> &ws, const Grp<G
         if (t < L) key[j] = (t < n_old) ? OLD[t] : ws.D[t];
     }
     LdsSpace::sync();
-    uint64_t un = 0ull;     // bit j: own element j not placed yet (NJ can be 33)
+    // peel rounds: the still-unplaced element with the largest position wins its bucket in every round.  Branch-free per
+    // element: a placed (or absent) element sends the value 0, which atomicMax ignores.
+    bool pend[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         bk[j] = mod_magic(key[j], B, M, S);
         rho[j] = 0u;
-        if (t0 + j < L) un |= 1ull << j;
+        pend[j] = t0 + j < L;
     }
-    // peel rounds: the still-unplaced element with the largest position wins its bucket in every round
     for (uint32_t round = 1; round <= L; ++round) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            if ((un >> j) & 1ull) atomicMax(&ws.TBL[bk[j]], (round << 16) | (t0 + j));
+        for (int j = 0; j < NJ; ++j) atomicMax(&ws.TBL[bk[j]], pend[j] ? ((round << 16) | (t0 + j)) : 0u);
         LdsSpace::sync();
         uint32_t v[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) v[j] = ((un >> j) & 1ull) ? ws.TBL[bk[j]] : 0xFFFFFFFFu;
+        for (int j = 0; j < NJ; ++j) v[j] = ws.TBL[bk[j]];
+        bool left = false;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            if (((un >> j) & 1ull) && (v[j] & 0xFFFFu) == t0 + j) { rho[j] = round - 1u; un &= ~(1ull << j); }
+        for (int j = 0; j < NJ; ++j) {
+            const bool won = pend[j] && (v[j] & 0xFFFFu) == t0 + j;
+            rho[j] = won ? round - 1u : rho[j];
+            pend[j] = pend[j] && !won;
+            left = left || pend[j];
+        }
         LdsSpace::sync();
-        if (!g.any(un != 0ull)) break;
+        if (!g.any(left)) break;
     }
     // bucket entry = (size << 16) | first position.  Buckets are laid out by DESCENDING first position.
     uint32_t gs[NJ], mine_total = 0u;
@@ -320,6 +340,78 @@ __device__ __forceinline__ void stage_fast(const Work<LdsSpace> &ws, const Grp<G
     LdsSpace::sync();
 }
 
+// The LAST stage only has to name the element at iteration position `rsel`, so nothing is ranked or materialised:
+// one atomicMin (first position of every bucket) and one atomicAdd (its size) on the same word, a scan of the sizes
+// over the bucket leaders to find the bucket that holds position rsel, and ballots among that bucket's few members.
+template <int GS, int NJ>
+__device__ __forceinline__ uint32_t stage_final(const Work<LdsSpace> &ws, const Grp<GS> &g, const uint32_t *OLD, uint32_t n_old,
+                                                uint32_t L, uint32_t B, uint32_t M, uint32_t S, uint32_t rsel) {
+    const uint32_t t0 = (uint32_t)g.lane * NJ;
+    uint32_t key[NJ], bk[NJ];
+    bool valid[NJ];
+    {
+        uint4 *T4 = reinterpret_cast<uint4 *>(ws.TBL);
+        const uint32_t n4 = (B + 3u) >> 2;
+        for (uint32_t i = g.lane; i < n4; i += GS) T4[i] = make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const uint32_t t = t0 + j;
+        valid[j] = t < L;
+        key[j] = 0u;
+        if (valid[j]) key[j] = (t < n_old) ? OLD[t] : ws.D[t];
+    }
+    LdsSpace::sync();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        bk[j] = mod_magic(key[j], B, M, S);
+        atomicMin(&ws.TBL[bk[j]], valid[j] ? t0 + j : 0xFFFFu);
+    }
+    LdsSpace::sync();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) atomicAdd(&ws.TBL[bk[j]], valid[j] ? 0x10000u : 0u);
+    LdsSpace::sync();
+    uint32_t gs[NJ], mine_total = 0u;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) gs[j] = ws.TBL[bk[j]];                 // (size << 16) | first position
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        gs[j] = (valid[j] && (gs[j] & 0xFFFFu) == t0 + j) ? (gs[j] >> 16) : 0u;
+        mine_total += gs[j];
+    }
+    const uint32_t incl = g.prefix_incl(mine_total);
+    uint32_t run = g.last(incl) - incl;                                   // positions taken by buckets led from higher lanes
+    bool hit = false;
+    uint32_t hb = 0u, ho = 0u;
+#pragma unroll
+    for (int j = NJ - 1; j >= 0; --j) {
+        if (gs[j] && rsel >= run && rsel < run + gs[j]) { hit = true; hb = bk[j]; ho = rsel - run; }
+        run += gs[j];
+    }
+    const uint64_t hm = g.ballot(hit);
+    const int hsrc = hm ? (__ffsll((long long)hm) - 1) : 0;
+    const uint32_t bstar = g.bcast(hb, hsrc), off = g.bcast(ho, hsrc);
+    // members of that bucket are visited in DESCENDING position: the answer has exactly `off` members above it
+    const uint64_t above = (g.lane == GS - 1) ? 0ull : ((~0ull << (g.lane + 1)) & ((GS == 64) ? ~0ull : ((1ull << (GS & 63)) - 1ull)));
+    bool cand[NJ];
+    uint32_t higher = 0u;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        cand[j] = valid[j] && bk[j] == bstar;
+        higher += (uint32_t)__popcll(g.ballot(cand[j]) & above);
+    }
+    bool have = false;
+    uint32_t mine = 0u, own_above = 0u;
+#pragma unroll
+    for (int j = NJ - 1; j >= 0; --j) {
+        if (cand[j]) { if (higher + own_above == off) { have = true; mine = key[j]; } own_above += 1u; }
+    }
+    const uint64_t mk = g.ballot(have);
+    const int src = mk ? (__ffsll((long long)mk) - 1) : 0;
+    LdsSpace::sync();
+    return g.bcast(mine, src);
+}
+
 // LDS tiers: iteration-order selection with the register-resident stages; `nvalid` = number of leading stages whose
 // materialised order is still valid (the candidates they cover did not change since they were computed).
 template <int GS, int MAXPER>
@@ -328,27 +420,37 @@ __device__ __forceinline__ uint32_t select_lds(const Work<LdsSpace> &ws, const G
     while (fs < kChainLen - 1 && d_chain.B[fs] < c) ++fs;
     bool have = false;
     uint32_t mine = 0u;
-    for (int stage = nvalid < fs ? nvalid : fs; stage <= fs; ++stage) {
+    for (int stage = nvalid < fs ? nvalid : fs; stage < fs; ++stage) {      // stages that are materialised (and then cached)
         const uint32_t B = d_chain.B[stage], M = d_chain.M[stage], S = d_chain.S[stage];
-        const uint32_t L = c < B ? c : B;
-        const bool final = stage == fs;
         const uint32_t *OLD = stage ? ws.ORD + d_chain.O[stage - 1] : ws.D;
         uint32_t *NEW = ws.ORD + d_chain.O[stage];
         const uint32_t n_old = stage ? d_chain.B[stage - 1] : 0u;
-        const uint32_t per = (L + GS - 1) / GS;
-        if (per <= 1) stage_fast<GS, 1>(ws, g, OLD, NEW, n_old, L, B, M, S, final, rsel, have, mine);
-        else if (per <= 3) stage_fast<GS, 3>(ws, g, OLD, NEW, n_old, L, B, M, S, final, rsel, have, mine);
-        else if (per <= 5) stage_fast<GS, 5>(ws, g, OLD, NEW, n_old, L, B, M, S, final, rsel, have, mine);
-        else if (per <= 9 || MAXPER <= 9) stage_fast<GS, 9>(ws, g, OLD, NEW, n_old, L, B, M, S, final, rsel, have, mine);
+        const uint32_t per = (B + GS - 1) / GS;                             // these stages are full: L == B
+        if (per <= 1) stage_fast<GS, 1>(ws, g, OLD, NEW, n_old, B, B, M, S, false, rsel, have, mine);
+        else if (per <= 3) stage_fast<GS, 3>(ws, g, OLD, NEW, n_old, B, B, M, S, false, rsel, have, mine);
+        else if (per <= 5) stage_fast<GS, 5>(ws, g, OLD, NEW, n_old, B, B, M, S, false, rsel, have, mine);
+        else if (per <= 9 || MAXPER <= 9) stage_fast<GS, 9>(ws, g, OLD, NEW, n_old, B, B, M, S, false, rsel, have, mine);
         else if constexpr (MAXPER > 9) {
-            if (per <= 17) stage_fast<GS, 17>(ws, g, OLD, NEW, n_old, L, B, M, S, final, rsel, have, mine);
-            else stage_fast<GS, 33>(ws, g, OLD, NEW, n_old, L, B, M, S, final, rsel, have, mine);
+            if (per <= 17) stage_fast<GS, 17>(ws, g, OLD, NEW, n_old, B, B, M, S, false, rsel, have, mine);
+            else stage_fast<GS, 33>(ws, g, OLD, NEW, n_old, B, B, M, S, false, rsel, have, mine);
         }
-        if (!final) nvalid = stage + 1;
+        nvalid = stage + 1;
     }
-    const uint64_t mk = g.ballot(have);
-    const int src = mk ? (__ffsll((long long)mk) - 1) : 0;
-    return g.bcast(mine, src);
+    {
+        const uint32_t B = d_chain.B[fs], M = d_chain.M[fs], S = d_chain.S[fs];
+        const uint32_t *OLD = fs ? ws.ORD + d_chain.O[fs - 1] : ws.D;
+        const uint32_t n_old = fs ? d_chain.B[fs - 1] : 0u;
+        const uint32_t per = (c + GS - 1) / GS;
+        if (per <= 1) return stage_final<GS, 1>(ws, g, OLD, n_old, c, B, M, S, rsel);
+        else if (per <= 3) return stage_final<GS, 3>(ws, g, OLD, n_old, c, B, M, S, rsel);
+        else if (per <= 5) return stage_final<GS, 5>(ws, g, OLD, n_old, c, B, M, S, rsel);
+        else if (per <= 9 || MAXPER <= 9) return stage_final<GS, 9>(ws, g, OLD, n_old, c, B, M, S, rsel);
+        else if constexpr (MAXPER > 9) {
+            if (per <= 17) return stage_final<GS, 17>(ws, g, OLD, n_old, c, B, M, S, rsel);
+            return stage_final<GS, 33>(ws, g, OLD, n_old, c, B, M, S, rsel);
+        }
+    }
+    return mine;
 }
 
 template <int GS, int MAXPER> __device__ __forceinline__ uint32_t select_any(const Work<LdsSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel, int &nvalid) {
@@ -366,8 +468,7 @@ template <int GS, int MAXPER> __device__ __forceinline__ uint32_t select_any(con
 template <int GS, class SP, bool ADD>
 __device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, const UgsPlanDev &P, int64_t rbase, uint32_t v,
                                          uint32_t root_vi, uint32_t size, uint32_t &c, uint32_t &hcount, uint32_t &seq,
-                                         uint32_t &ecount) {
-    const int64_t r0 = P.rowptr[rbase + v], r1 = P.rowptr[rbase + v + 1];
+                                         uint32_t &ecount, int64_t r0, int64_t r1) {
     for (int64_t base = r0; base < r1; base += GS) {
         const int64_t p = base + g.lane;
         bool cand = false;
@@ -436,6 +537,8 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
         if (g.lane == 0) a.counts[row_rel] = 0;
         return true;
     }
+    STAMP_DECL;
+    STAMP_BEGIN();
     Rng rng;
     rng.init(a.seed64 + (uint64_t)i * 0x9e3779b97f4a7c15ull);
     uint32_t root_vi, root_v;
@@ -463,13 +566,20 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
     SP::sync();
     uint32_t size = 1, c = 0, hcount = 1, seq = UGS_KMAX, ecount = 0;
     int nvalid = 0;           // leading stages of the order computation that are still valid
-    bool ok = (k > 1) ? scan_row<GS, SP, true>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, seq, ecount)
-                      : scan_row<GS, SP, false>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, seq, ecount);
+    STAMP_END(0);
+    int64_t r0 = P.rowptr[gd.rbase + root_v], r1 = P.rowptr[gd.rbase + root_v + 1];
+    bool ok = (k > 1) ? scan_row<GS, SP, true>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, seq, ecount, r0, r1)
+                      : scan_row<GS, SP, false>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, seq, ecount, r0, r1);
+    STAMP_END(1);
     if (!ok) return false;
     for (int step = 1; step < k; ++step) {
         if (c == 0) break;                                                    // growth failed: partial row
         const uint32_t rsel = (uint32_t)(rng.next() % (uint64_t)c);
+        STAMP_END(4);
         const uint32_t w = select_any<GS, MAXPER>(ws, g, c, rsel, nvalid);
+        r0 = P.rowptr[gd.rbase + w];               // issued now, consumed after the candidate list has been updated
+        r1 = P.rowptr[gd.rbase + w + 1];
+        STAMP_END(2);
         // move w from the candidates to the sample: drop it from D keeping the order of the others
         uint32_t q = c;
         for (uint32_t t0 = 0; t0 < c && q == c; t0 += 4 * GS) {        // 4 chunks per LDS round trip
@@ -505,14 +615,18 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
         }
         size += 1;
         SP::sync();
-        ok = (step < k - 1) ? scan_row<GS, SP, true>(ws, g, P, gd.rbase, w, root_vi, size, c, hcount, seq, ecount)
-                            : scan_row<GS, SP, false>(ws, g, P, gd.rbase, w, root_vi, size, c, hcount, seq, ecount);
+        STAMP_END(3);
+        ok = (step < k - 1) ? scan_row<GS, SP, true>(ws, g, P, gd.rbase, w, root_vi, size, c, hcount, seq, ecount, r0, r1)
+                            : scan_row<GS, SP, false>(ws, g, P, gd.rbase, w, root_vi, size, c, hcount, seq, ecount, r0, r1);
+        STAMP_END(1);
         if (!ok) return false;
     }
     // nodes row: growth order, -1 padded (reference src/sampler.cpp:205-216, src/ugs_sampler_batch_extension.cpp:188-196)
     const int64_t off = gd.node_lo + a.extra_node_off;
     for (int j = g.lane; j < k; j += GS) out[j] = (j < (int)size) ? (int64_t)SV[j] + off : (int64_t)-1;
     if (g.lane == 0) a.counts[row_rel] = (size == (uint32_t)k) ? ecount : 0u;   // incomplete rows carry no edges (:219-223)
+    STAMP_END(5);
+    STAMP_FLUSH(g.lane);
     return true;
 }
 
@@ -522,7 +636,8 @@ template <int CAP> struct TierCfg {
     static constexpr int ORDW = (int)((ord_words_before(NSTAGE) + 3u) & ~3u);     // 104 / 492 / 2144 words
     static constexpr int BCAP = CAP <= 64 ? 127 : (CAP <= 512 ? 541 : 2357);      // smallest chain value >= CAP
     static constexpr int BCAP_A = (BCAP + 3) & ~3;
-    static constexpr int HS = CAP <= 64 ? 128 : (CAP <= 512 ? 1024 : 4096);
+    static constexpr int HS = CAP <= 64 ? 128 : (CAP <= 512 ? 512 : 4096);
+    static constexpr int HLIMIT = CAP <= 512 && CAP > 64 ? HS / 8 * 7 : HS / 4 * 3;   // max distinct vertices a walk may have seen
     static constexpr int WORDS = CAP /*D*/ + ORDW + BCAP_A /*TBL*/ + 2 * HS /*HK,HP*/ + UGS_KMAX /*SV*/;
 };
 
@@ -545,7 +660,7 @@ __global__ __launch_bounds__(BLOCK) void ugs_walk_lds(UgsWalkArgs a) {
     uint32_t *SV = ws.HP + Cfg::HS;
     ws.cap = CAP;
     ws.hmask = Cfg::HS - 1;
-    ws.hlimit = Cfg::HS / 4 * 3;
+    ws.hlimit = Cfg::HLIMIT;
     const int64_t total = a.in_list ? (int64_t)*a.in_count : a.row_count;
     const int64_t ngroups = (int64_t)gridDim.x * GROUPS;
     for (int64_t it = (int64_t)blockIdx.x * GROUPS + gib; it < total; it += ngroups) {
@@ -721,6 +836,14 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------------------
+#ifdef UGS_STAMPS
+extern "C" int ugs_debug_read_stamps(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ugs_stamp_buffer), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ugs_stamp_buffer), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+
 int64_t ugs_scan_tmp_words(int64_t rows) { return (rows + kScanTile - 1) / kScanTile + 1; }
 
 int64_t ugs_global_ws_words(int64_t gcap, int64_t gbcap, int64_t gpcap, int64_t ghs) {
@@ -755,7 +878,7 @@ hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, hipStream_t 
     if (cus <= 0) cus = 256;
     switch (tier) {
     case UGS_TIER_S: return launch_lds<8, 64, 256>(a, cus, 2, s, info, "ugs_walk_lds<8,64>");
-    case UGS_TIER_M: return launch_lds<64, 512, 64>(a, cus, 11, s, info, "ugs_walk_lds<64,512>");
+    case UGS_TIER_M: return launch_lds<64, 512, 64>(a, cus, 15, s, info, "ugs_walk_lds<64,512>");
     case UGS_TIER_L: return launch_lds<64, 2048, 64>(a, cus, 2, s, info, "ugs_walk_lds<64,2048>");
     default: {
         int64_t grid = a.gws_words_per_group > 0 ? a.gws_groups : 0;
