@@ -260,83 +260,96 @@ __device__ __forceinline__ uint32_t select_in_order(const Work<SP> &ws, const Gr
     return ws.D[0];   // unreachable for c within the chain
 }
 
-// One stage of the order computation with every element held in REGISTERS: lane l owns the NJ consecutive positions
-// [l*NJ, l*NJ + NJ) (NJ odd -> the lane stride is conflict-free on the 32 LDS banks), LDS operations of a phase are
-// issued back to back and waited for once, the bucket starts come from per-lane running sums plus ONE group-wide scan.
+// One NON-FINAL stage of the order computation (the table is full: B elements into B buckets) with every element held in
+// REGISTERS: lane l owns the NJ consecutive positions [l*NJ, l*NJ + NJ) (NJ odd -> the lane stride is conflict-free on
+// the 32 LDS banks); the LDS operations of a phase are issued back to back and waited for once.
+//   1. atomicMin  -> first position of every bucket           2. atomicAdd -> its size (same word: size<<16 | first)
+//   3. ONE group-wide DPP scan of the sizes over the bucket leaders (buckets are laid out by DESCENDING first position)
+//      -> leaders store their bucket's start rank
+//   4. atomicAdd-with-return hands every element the bucket's start and an arrival slot; the element's position goes to
+//      a uint16 scratch list at start + slot (behind the bucket table)
+//   5. every element reads its bucket's (tiny) list and counts the members above it -> rank = start + count; scatter.
+// No loop over rounds: nine LDS round trips whatever the bucket sizes (a bucket of more than UNR members takes a short
+// extra loop).
 template <int GS, int NJ>
-__device__ __forceinline__ void stage_fast(const Work<LdsSpace> &ws, const Grp<GS> &g, const uint32_t *OLD, uint32_t *NEW,
-                                           uint32_t n_old, uint32_t L, uint32_t B, uint32_t M, uint32_t S, bool final,
-                                           uint32_t rsel, bool &have, uint32_t &mine) {
+__device__ __forceinline__ void stage_mat(const Work<LdsSpace> &ws, const Grp<GS> &g, const uint32_t *OLD, uint32_t *NEW,
+                                          uint32_t n_old, uint32_t B, uint32_t M, uint32_t S) {
+    constexpr int UNR = NJ <= 5 ? 6 : 4;
     const uint32_t t0 = (uint32_t)g.lane * NJ;
-    uint32_t key[NJ], bk[NJ], rho[NJ];
-    {   // clear the bucket table with 16-byte stores
+    uint32_t key[NJ], bk[NJ];
+    bool valid[NJ];
+    {
         uint4 *T4 = reinterpret_cast<uint4 *>(ws.TBL);
         const uint32_t n4 = (B + 3u) >> 2;
-        for (uint32_t i = g.lane; i < n4; i += GS) T4[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t i = g.lane; i < n4; i += GS) T4[i] = make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu);
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const uint32_t t = t0 + j;
+        valid[j] = t < B;
         key[j] = 0u;
-        if (t < L) key[j] = (t < n_old) ? OLD[t] : ws.D[t];
+        if (valid[j]) key[j] = (t < n_old) ? OLD[t] : ws.D[t];
     }
     LdsSpace::sync();
-    // peel rounds: the still-unplaced element with the largest position wins its bucket in every round.  Branch-free per
-    // element: a placed (or absent) element sends the value 0, which atomicMax ignores.
-    bool pend[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         bk[j] = mod_magic(key[j], B, M, S);
-        rho[j] = 0u;
-        pend[j] = t0 + j < L;
+        atomicMin(&ws.TBL[bk[j]], valid[j] ? t0 + j : 0xFFFFu);
     }
-    for (uint32_t round = 1; round <= L; ++round) {
+    LdsSpace::sync();
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) atomicMax(&ws.TBL[bk[j]], pend[j] ? ((round << 16) | (t0 + j)) : 0u);
-        LdsSpace::sync();
-        uint32_t v[NJ];
+    for (int j = 0; j < NJ; ++j) atomicAdd(&ws.TBL[bk[j]], valid[j] ? 0x10000u : 0u);
+    LdsSpace::sync();
+    uint32_t cnt[NJ], gs[NJ], mine_total = 0u;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) v[j] = ws.TBL[bk[j]];
-        bool left = false;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const bool won = pend[j] && (v[j] & 0xFFFFu) == t0 + j;
-            rho[j] = won ? round - 1u : rho[j];
-            pend[j] = pend[j] && !won;
-            left = left || pend[j];
-        }
-        LdsSpace::sync();
-        if (!g.any(left)) break;
-    }
-    // bucket entry = (size << 16) | first position.  Buckets are laid out by DESCENDING first position.
-    uint32_t gs[NJ], mine_total = 0u;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) gs[j] = (t0 + j < L) ? ws.TBL[bk[j]] : 0u;
+    for (int j = 0; j < NJ; ++j) gs[j] = ws.TBL[bk[j]];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        gs[j] = ((t0 + j < L) && (gs[j] & 0xFFFFu) == t0 + j) ? (gs[j] >> 16) : 0u;    // size if this element leads its bucket
+        cnt[j] = valid[j] ? (gs[j] >> 16) : 0u;
+        gs[j] = (valid[j] && (gs[j] & 0xFFFFu) == t0 + j) ? cnt[j] : 0u;      // size, if this element leads its bucket
         mine_total += gs[j];
     }
     const uint32_t incl = g.prefix_incl(mine_total);
-    uint32_t run = g.last(incl) - incl;          // elements of buckets led from higher lanes
-    LdsSpace::sync();                             // every lane has read the sizes before leaders overwrite them
+    uint32_t run = g.last(incl) - incl;                                       // ranks taken by buckets led from higher lanes
+    LdsSpace::sync();                                                          // every lane has read the sizes
 #pragma unroll
     for (int j = NJ - 1; j >= 0; --j) {
-        if (gs[j]) ws.TBL[bk[j]] = run;           // bucket start rank
+        if (gs[j]) ws.TBL[bk[j]] = run;                                        // arrivals 0 | bucket start
         run += gs[j];
     }
     LdsSpace::sync();
+    uint16_t *POS = reinterpret_cast<uint16_t *>(ws.TBL + ((B + 3u) & ~3u));
     uint32_t st[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) st[j] = (t0 + j < L) ? ws.TBL[bk[j]] : 0u;
+    for (int j = 0; j < NJ; ++j) st[j] = atomicAdd(&ws.TBL[bk[j]], valid[j] ? 0x10000u : 0u);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        if (t0 + j < L) {
-            const uint32_t rank = st[j] + rho[j];
-            if (final) { if (rank == rsel) { have = true; mine = key[j]; } }
-            else NEW[rank] = key[j];
-        }
+        const uint32_t slot = st[j] >> 16;
+        st[j] &= 0xFFFFu;
+        if (valid[j]) POS[st[j] + slot] = (uint16_t)(t0 + j);
     }
+    LdsSpace::sync();
+    uint32_t rho[NJ];
+    bool more = false;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        uint32_t pv[UNR];
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) pv[i] = POS[st[j] + i];                  // reads past the list stay inside the table
+        rho[j] = 0u;
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) rho[j] += ((uint32_t)i < cnt[j] && pv[i] > t0 + j) ? 1u : 0u;
+        more = more || cnt[j] > (uint32_t)UNR;
+    }
+    if (g.any(more)) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            for (uint32_t i = UNR; i < cnt[j]; ++i) rho[j] += (POS[st[j] + i] > t0 + j) ? 1u : 0u;
+    }
+    LdsSpace::sync();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+        if (valid[j]) NEW[st[j] + rho[j]] = key[j];
     LdsSpace::sync();
 }
 
@@ -426,13 +439,13 @@ __device__ __forceinline__ uint32_t select_lds(const Work<LdsSpace> &ws, const G
         uint32_t *NEW = ws.ORD + d_chain.O[stage];
         const uint32_t n_old = stage ? d_chain.B[stage - 1] : 0u;
         const uint32_t per = (B + GS - 1) / GS;                             // these stages are full: L == B
-        if (per <= 1) stage_fast<GS, 1>(ws, g, OLD, NEW, n_old, B, B, M, S, false, rsel, have, mine);
-        else if (per <= 3) stage_fast<GS, 3>(ws, g, OLD, NEW, n_old, B, B, M, S, false, rsel, have, mine);
-        else if (per <= 5) stage_fast<GS, 5>(ws, g, OLD, NEW, n_old, B, B, M, S, false, rsel, have, mine);
-        else if (per <= 9 || MAXPER <= 9) stage_fast<GS, 9>(ws, g, OLD, NEW, n_old, B, B, M, S, false, rsel, have, mine);
+        if (per <= 1) stage_mat<GS, 1>(ws, g, OLD, NEW, n_old, B, M, S);
+        else if (per <= 3) stage_mat<GS, 3>(ws, g, OLD, NEW, n_old, B, M, S);
+        else if (per <= 5) stage_mat<GS, 5>(ws, g, OLD, NEW, n_old, B, M, S);
+        else if (per <= 9 || MAXPER <= 9) stage_mat<GS, 9>(ws, g, OLD, NEW, n_old, B, M, S);
         else if constexpr (MAXPER > 9) {
-            if (per <= 17) stage_fast<GS, 17>(ws, g, OLD, NEW, n_old, B, B, M, S, false, rsel, have, mine);
-            else stage_fast<GS, 33>(ws, g, OLD, NEW, n_old, B, B, M, S, false, rsel, have, mine);
+            if (per <= 17) stage_mat<GS, 17>(ws, g, OLD, NEW, n_old, B, M, S);
+            else stage_mat<GS, 33>(ws, g, OLD, NEW, n_old, B, M, S);
         }
         nvalid = stage + 1;
     }
@@ -779,14 +792,21 @@ __global__ __launch_bounds__(kScanBlock) void ugs_scan_small(const uint32_t *cou
 // ------------------------------------------------------------------------------------------------------------------
 // fill kernel: induced edges of complete rows, vertex order j then CSR position p (reference src/sampler.cpp:232-243)
 // ------------------------------------------------------------------------------------------------------------------
+// The k adjacency rows of a sample are FLATTENED into one index space e = 0 .. sum(deg)-1 (row-major = the required
+// output order), so every lane's loads are independent: two dependent memory round trips per sample (row bounds, then all
+// adjacency entries) instead of two per sampled vertex.
 template <int GS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
     constexpr int GROUPS = BLOCK / GS;
     __shared__ uint32_t sv_all[GROUPS * UGS_KMAX];
+    __shared__ uint32_t ps_all[GROUPS * (UGS_KMAX + 1)];
+    __shared__ int64_t r0_all[GROUPS * UGS_KMAX];
     Grp<GS> g;
     g.init();
     const int gib = (int)threadIdx.x / GS;
     uint32_t *SV = sv_all + gib * UGS_KMAX;
+    uint32_t *PS = ps_all + gib * (UGS_KMAX + 1);       // PS[j] = entries of rows < j
+    int64_t *R0 = r0_all + gib * UGS_KMAX;
     const UgsPlanDev &P = a.plan;
     const int k = a.k;
     const int64_t ngroups = (int64_t)gridDim.x * GROUPS;
@@ -800,30 +820,51 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
         const UgsGraphDesc gd = P.graphs[gi];
         const int64_t off = gd.node_lo + a.extra_node_off;
         const int64_t *nrow = a.nodes + row_rel * k;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-        for (int j = g.lane; j < k; j += GS) SV[j] = (uint32_t)(nrow[j] - off);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-        int64_t w_off = e0;
-        for (int j = 0; j < k; ++j) {
-            const uint32_t u = SV[j];
+        LdsSpace::sync();
+        for (int j = g.lane; j < k; j += GS) {
+            const uint32_t u = (uint32_t)(nrow[j] - off);
             const int64_t r0 = P.rowptr[gd.rbase + u], r1 = P.rowptr[gd.rbase + u + 1];
-            for (int64_t base = r0; base < r1; base += GS) {
-                const int64_t p = base + g.lane;
-                int l = -1;
-                if (p < r1) {
-                    const uint32_t w = (uint32_t)P.adj[p].x;
-                    for (int t = 0; t < k; ++t) if (SV[t] == w) { l = t; break; }
+            SV[j] = u;
+            R0[j] = r0;
+            PS[j + 1] = (uint32_t)(r1 - r0);
+        }
+        LdsSpace::sync();
+        if (g.lane == 0) { uint32_t acc = 0; PS[0] = 0; for (int j = 1; j <= k; ++j) { acc += PS[j]; PS[j] = acc; } }
+        LdsSpace::sync();
+        const uint32_t T = PS[k];
+        int64_t w_off = e0;
+        for (uint32_t cb = 0; cb < T; cb += 4 * GS) {
+            uint32_t wv[4];
+            int jj[4];
+            int64_t pp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t e = cb + u * GS + g.lane;
+                wv[u] = kEmpty; jj[u] = 0; pp[u] = 0;
+                if (e < T) {
+                    int j = 0;
+                    for (int t = 1; t < k; ++t) j += (PS[t] <= e) ? 1 : 0;       // row of flattened entry e
+                    jj[u] = j;
+                    pp[u] = R0[j] + (int64_t)(e - PS[j]);
+                    wv[u] = (uint32_t)P.adj[pp[u]].x;
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (cb + u * GS >= T) break;
+                int l = -1;
+                if (wv[u] != kEmpty) { for (int t = 0; t < k; ++t) if (SV[t] == wv[u]) { l = t; break; } }
                 const uint64_t mk = g.ballot(l >= 0);
                 if (l >= 0) {
                     const int64_t pos = w_off + __popcll(mk & g.lt_mask());
+                    const int j = jj[u];
                     int64_t uf, vf;
                     if (a.mode == 0) { uf = j; vf = l; }
                     else if (a.mode == 1) { uf = i * k + j; vf = i * k + l; }
                     else { uf = nrow[j]; vf = nrow[l]; }
                     a.edge_index[pos] = uf;
                     a.edge_index[a.ld + pos] = vf;
-                    a.edge_src[pos] = (int64_t)P.ecol[p];
+                    a.edge_src[pos] = (int64_t)P.ecol[pp[u]];
                 }
                 w_off += __popcll(mk);
             }
@@ -911,7 +952,7 @@ hipError_t ugs_launch_fill(const UgsFillArgs &a, int wide, int cus, hipStream_t 
         int64_t grid = (a.row_count + GROUPS - 1) / GROUPS;
         if (grid > (int64_t)cus * 8) grid = (int64_t)cus * 8;
         hipLaunchKernelGGL((ugs_fill<64, BLOCK>), dim3((unsigned)grid), dim3(BLOCK), 0, s, a);
-        if (info) { info->name = "ugs_fill<64>"; info->grid = (int)grid; info->block = BLOCK; info->lds_bytes = GROUPS * UGS_KMAX * 4; }
+        if (info) { info->name = "ugs_fill<64>"; info->grid = (int)grid; info->block = BLOCK; info->lds_bytes = GROUPS * UGS_KMAX * 20; }
     } else {
         constexpr int BLOCK = 256, GROUPS = 32;
         int64_t grid = (a.row_count + GROUPS - 1) / GROUPS;
