@@ -8,7 +8,9 @@ A *step* is one pass of the hot path over one batch: walk kernel(s) + scan + fil
 tensors (nodes, edge_index, edge_ptr, edge_src) in HBM from a plan (preprocessed graph batch) that is already resident
 in HBM -- the state the reference is in with a warm preprocessing LRU.  Default workload: BASELINE.json configs[4], the
 Erdos-Renyi graph |V|=1M, 20M columns, k=8, 1M samples per GPU (weak scaling: N GPUs produce N*1M rows of the same job,
-rank r owning rows [r*1M, (r+1)*1M); for N>1 every step also collates the batch on rank 0 over RCCL).
+rank r owning rows [r*1M, (r+1)*1M); for N>1 every step also collates the batch on rank 0 over RCCL -- on a side
+stream, double-buffered, so the collation of batch s overlaps the sampling of batch s+1; all K collations are inside the
+timed region).
 The seed changes every step (42 + step) so no step can reuse a previous step's output.
 """
 import argparse
@@ -47,6 +49,15 @@ def split_algorithmic_bytes(nodes, edge_ptr, k, deg):
 
 
 def main():
+    # Libraries (RCCL prints a version banner) must not pollute stdout: fd 1 is pointed at stderr for the whole run and the
+    # single JSON line goes to the saved, real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(real_stdout, (line + "\n").encode())
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -56,6 +67,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="rows timed on the CPU baseline (default: sized per workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--force-collate", action="store_true", help="run the multi-GPU collation path even with one rank (rehearsal)")
     args = ap.parse_args()
 
     import numpy as np
@@ -73,8 +85,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    if world > 1 or args.force_collate:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", os.environ.get("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- workload + plan (host preprocessing and upload are NOT timed: warm-cache state) --------------------------
     t0 = time.time()
@@ -94,39 +108,70 @@ def main():
     row_begin, row_count = ud.shard_range(total_rows, rank, world)
     assert row_count == rows_local
 
-    nodes_buf = torch.empty((row_count, k), dtype=torch.int64, device=dev)
-    eptr_buf = torch.empty((row_count + 1,), dtype=torch.int64, device=dev)
+    use_collate = world > 1 or args.force_collate
+    nsets = 2 if use_collate else 1          # double buffering: step s samples into set s%2 while set (s-1)%2 is collated
+    nodes_bufs = [torch.empty((row_count, k), dtype=torch.int64, device=dev) for _ in range(nsets)]
+    eptr_bufs = [torch.empty((row_count + 1,), dtype=torch.int64, device=dev) for _ in range(nsets)]
+    nodes_buf, eptr_buf = nodes_bufs[0], eptr_bufs[0]
     # edge capacity from one synchronous probe step (+5%); identical on every rank
     _, _, tot = plan.walk(m_total, args.mode, 41, row_begin, row_count, out=(nodes_buf, eptr_buf), sync=True)
     cap_t = torch.tensor([int(tot * 1.05) + 4096], dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
     cap = int(cap_t.item())
-    eidx_buf = torch.empty((2, cap), dtype=torch.int64, device=dev)
-    esrc_buf = torch.empty((cap,), dtype=torch.int64, device=dev)
+    eidx_bufs = [torch.empty((2, cap), dtype=torch.int64, device=dev) for _ in range(nsets)]
+    esrc_bufs = [torch.empty((cap,), dtype=torch.int64, device=dev) for _ in range(nsets)]
     totals = torch.zeros((args.steps + args.warmup + 1,), dtype=torch.int64, device=dev)
     node_bound = int(ptr[-1])
     edge_bound = max(node_bound, m_total * k)
+    main_stream = torch.cuda.current_stream()
+    side = torch.cuda.Stream(device=dev) if use_collate else None
+    ev_sampled = [torch.cuda.Event() for _ in range(nsets)]
+    ev_collated = [torch.cuda.Event() for _ in range(nsets)]
+    collated_once = [False] * nsets
 
-    def step(i):
-        seed = 42 + i
-        plan.walk(m_total, args.mode, seed, row_begin, row_count, out=(nodes_buf, eptr_buf), sync=False)
-        plan.fill(m_total, nodes_buf, eptr_buf, None, args.mode, row_begin, out=(eidx_buf, esrc_buf))
-        totals[i] = eptr_buf[-1]
-        if world > 1:     # the one exchange step: collate the finished batch on rank 0
-            return ud.collate((nodes_buf, eidx_buf, eptr_buf, esrc_buf), k, args.mode, node_bound, edge_bound, ei.shape[1], dst=0)
-        return None
+    def sample(i):
+        """walk + scan + fill of step i into buffer set i % nsets (asynchronous, main stream)"""
+        b = i % nsets
+        if use_collate and collated_once[b]:
+            main_stream.wait_event(ev_collated[b])            # the set is free once its previous batch has been collated
+        plan.walk(m_total, args.mode, 42 + i, row_begin, row_count, out=(nodes_bufs[b], eptr_bufs[b]), sync=False)
+        plan.fill(m_total, nodes_bufs[b], eptr_bufs[b], None, args.mode, row_begin, out=(eidx_bufs[b], esrc_bufs[b]))
+        totals[i] = eptr_bufs[b][-1]
+        if use_collate:
+            ev_sampled[b].record(main_stream)
 
-    for i in range(args.warmup):
-        step(i)
+    def collate_step(i):
+        """the one exchange step: collate batch i on rank 0 (side stream, overlaps the sampling of batch i+1)"""
+        b = i % nsets
+        with torch.cuda.stream(side):
+            side.wait_event(ev_sampled[b])
+            res = ud.collate((nodes_bufs[b], eidx_bufs[b], eptr_bufs[b], esrc_bufs[b]), k, args.mode, node_bound, edge_bound,
+                             ei.shape[1], dst=0)
+            ev_collated[b].record(side)
+        collated_once[b] = True
+        return res
+
+    def run_steps(first, count):
+        """`count` complete steps: every batch sampled AND (multi-GPU) collated inside the call"""
+        if count <= 0:
+            return
+        for i in range(first, first + count):
+            sample(i)
+            if use_collate and i > first:
+                collate_step(i - 1)
+        if use_collate:
+            collate_step(first + count - 1)
+            side.synchronize()
+
+    run_steps(0, args.warmup)
     torch.cuda.synchronize()
     plan.set_timing(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        step(i)
+    run_steps(args.warmup, args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -143,9 +188,8 @@ def main():
         raise SystemExit(f"edge capacity {cap} too small for {tmax}: result invalid")
 
     if rank != 0:
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()
         return
 
     value = total_rows * args.steps / elapsed
@@ -217,7 +261,7 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
            "config": {"workload": args.workload, "graphs": G, "columns": int(ei.shape[1]), "k": k, "rows_per_gpu": rows_local,
                       "global_rows": total_rows, "mode": args.mode, "sharding": f"rows{world}" if world > 1 else "none",
-                      "collate": "gather to rank 0 over RCCL every step" if world > 1 else "none (single GPU)"},
+                      "collate": "gather to rank 0 over RCCL every step, overlapped with the next step's sampling" if use_collate else "none (single GPU)"},
            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_checked_rows": parity_rows}
 
     # ---- secondary workloads (single GPU only, quick): the TU-shaped configurations of BASELINE.json -----------------
@@ -231,8 +275,9 @@ def main():
             except Exception as e:   # noqa: BLE001
                 extras[name] = {"error": str(e)}
         out["other_workloads"] = extras
-    print(json.dumps(out), flush=True)
-    if world > 1:
+    sys.stdout.flush()
+    emit(json.dumps(out))
+    if world > 1 or args.force_collate:
         dist.barrier()
         dist.destroy_process_group()
 
