@@ -124,6 +124,23 @@ int ugs_plan_fill(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
 int ugs_plan_last_launch(const ugs_plan *plan, char *name_buf, int name_buf_len, int *grid, int *block,
                          int *lds_bytes, int64_t *overflow_rows);
 
+/* ---- epsilon_uniform_sampler.sample_batch(edge_index, ptr, m_per_graph, k, mode, seed, epsilon): replaces the reference's
+ *      src/samplers/epsilon_uniform_sampler/src/epsilon_uniform_sampler.cpp:122-377.
+ *      Random frontier growth (:18-87) with acceptance min(1, eps/(w+eps)) (:238), at most max(10, 10/eps) attempts per
+ *      sample (:207); nodes of a sample sorted ascending (:256); edges = the batch columns with both endpoints in the sample,
+ *      in column order, each once (:265-291); mode 0 ("sample") numbers endpoints 0..k-1 by sorted position, any other mode
+ *      uses batch node ids; failed samples are rows of -1 without edges.
+ *      The reference is NOT deterministic here (per-thread generators seeded with the OpenMP thread id, dynamic schedule,
+ *      rows written in thread-completion order, :209-319).  This implementation is deterministic: one counter-based
+ *      generator per (row, attempt), rows in graph order; parity with the reference is statistical.
+ *      Same two-phase job protocol as ugs_sample_batch_*; finish writes nodes[G*m,k], edge_index[2,total],
+ *      edge_ptr[G*m+1], sample_ptr[G+1], edge_src[total]. */
+int ugs_eps_sample_batch_begin(const int64_t *edge_index, int64_t row_stride, int64_t num_cols, const int64_t *ptr,
+                               int64_t num_graphs, int m_per_graph, int k, int mode, uint64_t seed, double epsilon,
+                               ugs_job **job_out, int64_t *total_edges_out);
+int ugs_eps_sample_batch_finish(ugs_job *job, int64_t *nodes, int64_t *edge_index, int64_t *edge_ptr, int64_t *sample_ptr,
+                                int64_t *edge_src, int dst_is_device);
+
 /* Per-kernel timing with HIP events recorded on the launch stream (off by default).  get_timing synchronises the
  * recorded events, returns summed milliseconds and launch counts for [0] the first-tier walk kernel, [1] overflow
  * tiers + scan kernels, [2] the fill kernel since the last call, and clears them. */

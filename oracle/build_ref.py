@@ -70,5 +70,49 @@ def load():
     return mod
 
 
+EPS_REF = "/root/reference/src/samplers/epsilon_uniform_sampler"
+EPS_OUT = os.path.join(OUT_DIR, "epsilon_uniform_sampler" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_eps(force: bool = False) -> str:
+    """The reference epsilon_uniform_sampler module (one translation unit, OpenMP), same allocator-flag deviation as above
+    (oracle/ref_eps_unity.cpp).  Used only by tests/test_eps_oracle.py to pin oracle/eps_oracle.py statistically."""
+    if not os.path.isdir(EPS_REF):
+        raise FileNotFoundError(EPS_REF)
+    unity = os.path.join(HERE, "ref_eps_unity.cpp")
+    srcs = [unity, os.path.join(EPS_REF, "src", "epsilon_uniform_sampler.cpp"), os.path.join(EPS_REF, "include", "epsilon_uniform_sampler.hpp")]
+    if not force and os.path.exists(EPS_OUT) and all(os.path.getmtime(EPS_OUT) >= os.path.getmtime(x) for x in srcs):
+        return EPS_OUT
+    import pybind11
+    import torch
+    from torch.utils import cpp_extension as ce
+
+    os.makedirs(OUT_DIR, exist_ok=True)
+    cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-w", "-fopenmp", "-DTORCH_EXTENSION_NAME=epsilon_uniform_sampler",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           f"-I{EPS_REF}", f"-I{EPS_REF}/include"]
+    for p in ce.include_paths():
+        cmd.append(f"-I{p}")
+    cmd += [f"-I{pybind11.get_include()}", f"-I{sysconfig.get_paths()['include']}", unity, "-o", EPS_OUT]
+    for p in ce.library_paths():
+        cmd += [f"-L{p}", f"-Wl,-rpath,{p}"]
+    cmd += ["-lc10", "-ltorch", "-ltorch_cpu", "-ltorch_python"]
+    subprocess.run(cmd, check=True)
+    return EPS_OUT
+
+
+def load_eps():
+    import importlib.util
+
+    import torch  # noqa: F401
+
+    path = EPS_OUT if os.path.exists(EPS_OUT) else build_eps()
+    spec = importlib.util.spec_from_file_location("epsilon_uniform_sampler", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    print(build_eps(force="--force" in sys.argv))

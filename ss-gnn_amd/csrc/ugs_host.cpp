@@ -27,6 +27,14 @@
 struct ugs_plan;
 namespace { void plan_unref(ugs_plan *p); }
 
+// launcher of the epsilon_uniform kernels (ugs_eps.hip)
+struct UgsEpsLaunch {
+    const UgsGraphDesc *graphs; const int64_t *rowptr; const int32_t *nbr; const int32_t *ecs; int64_t num_graphs;
+    int32_t m, k, mode, max_attempts; uint64_t seed; double epsilon; int64_t rows;
+    int64_t *nodes; uint32_t *counts; const int64_t *edge_ptr; int64_t *edge_index; int64_t *edge_src; int64_t ld;
+};
+hipError_t ugs_eps_launch(const UgsEpsLaunch &l, int fill, int cus, hipStream_t s);
+
 namespace {
 
 thread_local std::string t_err;
@@ -552,6 +560,37 @@ TierChoice choose_tier(ugs_plan *p, int k) {
     return t;
 }
 
+// Column j belongs to graph g iff both endpoints lie in [ptr[g], ptr[g+1]) (the reference lets every graph scan every
+// column, src/ugs_sampler_batch_extension.cpp:41-75; with a monotone ptr the node ranges are disjoint and one pass with a
+// binary search gives the same per-graph lists, in column order).
+void assign_columns(const int64_t *src, const int64_t *dst, int64_t E, const int64_t *ptr, int64_t G,
+                    std::vector<int64_t> &cstart, std::vector<int64_t> &cols_of) {
+    cstart.assign((size_t)G + 1, 0);
+    cols_of.clear();
+    bool monotone = true;
+    for (int64_t g = 0; g < G; ++g) if (ptr[g + 1] < ptr[g]) { monotone = false; break; }
+    if (monotone) {
+        std::vector<int32_t> owner((size_t)E, -1);
+        for (int64_t j = 0; j < E; ++j) {
+            const int64_t u = src[j], v = dst[j];
+            if (G == 0 || u < ptr[0] || u >= ptr[G]) continue;
+            const int64_t g = (std::upper_bound(ptr, ptr + G + 1, u) - ptr) - 1;    // last g with ptr[g] <= u
+            if (g < 0 || g >= G || !(u >= ptr[g] && u < ptr[g + 1])) continue;
+            if (v >= ptr[g] && v < ptr[g + 1]) { owner[(size_t)j] = (int32_t)g; ++cstart[(size_t)g + 1]; }
+        }
+        for (int64_t g = 0; g < G; ++g) cstart[(size_t)g + 1] += cstart[(size_t)g];
+        cols_of.resize((size_t)cstart[(size_t)G]);
+        std::vector<int64_t> wr(cstart.begin(), cstart.end() - 1);
+        for (int64_t j = 0; j < E; ++j) if (owner[(size_t)j] >= 0) cols_of[(size_t)wr[(size_t)owner[(size_t)j]]++] = j;
+    } else {   // arbitrary ptr: every graph scans every column, like the reference
+        for (int64_t g = 0; g < G; ++g) {
+            const int64_t lo = ptr[g], hi = ptr[g + 1];
+            for (int64_t j = 0; j < E; ++j) if (src[j] >= lo && src[j] < hi && dst[j] >= lo && dst[j] < hi) cols_of.push_back(j);
+            cstart[(size_t)g + 1] = (int64_t)cols_of.size();
+        }
+    }
+}
+
 int ensure(PoolBuf &b, size_t bytes, int dev) {
     if (b.p && b.bytes >= bytes) return UGS_OK;
     pool_put(b);
@@ -676,31 +715,8 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
     if (int rc = device_ctx(dc)) return rc;
     const int64_t G = num_graphs, E = num_cols;
     const int64_t *src = edge_index, *dst = edge_index + row_stride;
-    // --- assign every column to the graph whose node range holds both endpoints, keeping column order --------------
-    bool monotone = true;
-    for (int64_t g = 0; g < G; ++g) if (ptr[g + 1] < ptr[g]) { monotone = false; break; }
-    std::vector<int64_t> cstart((size_t)G + 1, 0), cols_of;   // per-graph column lists, concatenated
-    if (monotone) {
-        std::vector<int32_t> owner((size_t)E, -1);
-        for (int64_t j = 0; j < E; ++j) {
-            const int64_t u = src[j], v = dst[j];
-            if (G == 0 || u < ptr[0] || u >= ptr[G]) continue;
-            int64_t g = (std::upper_bound(ptr, ptr + G + 1, u) - ptr) - 1;    // last g with ptr[g] <= u
-            while (g + 1 <= G - 1 && ptr[g + 1] <= u) ++g;
-            if (g < 0 || g >= G || !(u >= ptr[g] && u < ptr[g + 1])) continue;
-            if (v >= ptr[g] && v < ptr[g + 1]) { owner[(size_t)j] = (int32_t)g; ++cstart[(size_t)g + 1]; }
-        }
-        for (int64_t g = 0; g < G; ++g) cstart[(size_t)g + 1] += cstart[(size_t)g];
-        cols_of.resize((size_t)cstart[(size_t)G]);
-        std::vector<int64_t> wr(cstart.begin(), cstart.end() - 1);
-        for (int64_t j = 0; j < E; ++j) if (owner[(size_t)j] >= 0) cols_of[(size_t)wr[(size_t)owner[(size_t)j]]++] = j;
-    } else {   // arbitrary ptr: every graph scans every column, like the reference
-        for (int64_t g = 0; g < G; ++g) {
-            const int64_t lo = ptr[g], hi = ptr[g + 1];
-            for (int64_t j = 0; j < E; ++j) if (src[j] >= lo && src[j] < hi && dst[j] >= lo && dst[j] < hi) cols_of.push_back(j);
-            cstart[(size_t)g + 1] = (int64_t)cols_of.size();
-        }
-    }
+    std::vector<int64_t> cstart, cols_of;                      // per-graph column lists, concatenated
+    assign_columns(src, dst, E, ptr, G, cstart, cols_of);
     // --- per graph: renumber, hash, LRU lookup / preprocessing ------------------------------------------------------
     std::vector<PlanPiece> pieces((size_t)G);
     std::vector<int64_t> ru, rv, evicted;
@@ -927,12 +943,19 @@ struct ugs_job {
     int64_t extra = 0, rows = 0, total = 0, G = 0;
     bool batch = false;
     PoolBuf nodes, eptr;
+    // epsilon_uniform path
+    bool eps = false;
+    void *eps_blob = nullptr;
+    UgsEpsLaunch eps_l{};
+    PoolBuf eps_counts, eps_scantmp;
 };
 
 namespace {
 void free_job(ugs_job *j) {
     if (!j) return;
     pool_put(j->nodes); pool_put(j->eptr);
+    pool_put(j->eps_counts); pool_put(j->eps_scantmp);
+    if (j->eps_blob) (void)hipFree(j->eps_blob);
     plan_unref(j->plan);
     delete j;
 }
@@ -967,7 +990,12 @@ int finish_common(ugs_job *j, int64_t *nodes, int64_t *edge_index, int64_t *edge
             if (int r = pool_get((size_t)tot * sizeof(int64_t), j->dc.id, e_src)) return r;
             d_ei = static_cast<int64_t *>(e_idx.p); d_es = static_cast<int64_t *>(e_src.p);
         }
-        if (tot > 0) {
+        if (tot > 0 && j->eps) {
+            if (!d_ei || !d_es) return fail(UGS_E_BAD_ARG, "null edge output pointer");
+            UgsEpsLaunch l = j->eps_l;
+            l.edge_ptr = static_cast<const int64_t *>(j->eptr.p); l.edge_index = d_ei; l.edge_src = d_es; l.ld = tot;
+            HIP_TRY(ugs_eps_launch(l, 1, j->dc.cus, s));
+        } else if (tot > 0) {
             if (!d_ei || !d_es) return fail(UGS_E_BAD_ARG, "null edge output pointer");
             if (int r = ugs_plan_fill(j->plan, j->m, j->k, j->mode, j->extra, 0, rows, s, static_cast<const int64_t *>(j->nodes.p),
                                       static_cast<const int64_t *>(j->eptr.p), d_ei, tot, d_es)) return r;
@@ -1033,5 +1061,95 @@ int ugs_sample_batch_finish(ugs_job *job, int64_t *nodes, int64_t *edge_index, i
 }
 
 int ugs_job_cancel(ugs_job *job) { free_job(job); return UGS_OK; }
+
+// ---- epsilon_uniform_sampler.sample_batch (reference src/samplers/epsilon_uniform_sampler/src/epsilon_uniform_sampler.cpp) ----
+int ugs_eps_sample_batch_begin(const int64_t *edge_index, int64_t row_stride, int64_t num_cols, const int64_t *ptr, int64_t num_graphs,
+                               int m_per_graph, int k, int mode, uint64_t seed, double epsilon, ugs_job **job_out, int64_t *total_edges_out) {
+    if (!job_out || !ptr || num_graphs < 0 || num_cols < 0 || (num_cols > 0 && !edge_index)) return fail(UGS_E_BAD_ARG, "bad arguments to sample_batch");
+    if (!(epsilon > 0.0 && epsilon <= 1.0)) return fail(UGS_E_BAD_ARG, "epsilon must be in (0, 1]");
+    if (m_per_graph < 0) return fail(UGS_E_BAD_ARG, "m_per_graph must be >= 0");
+    if (k < 1) return fail(UGS_E_BAD_ARG, "k must be >= 1");
+    if (k > UGS_KMAX) return fail(UGS_E_UNSUPPORTED, "k > 32 is not supported by the HIP sampler");
+    if (num_cols >= ((int64_t)1 << 30)) return fail(UGS_E_UNSUPPORTED, "batch too large: columns must be < 2^30");
+    DeviceCtx dc;
+    if (int rc = device_ctx(dc)) return rc;
+    const int64_t G = num_graphs, E = num_cols;
+    const int64_t *src = edge_index, *dst = edge_index + row_stride;
+    std::vector<int64_t> cstart, cols_of;
+    assign_columns(src, dst, E, ptr, G, cstart, cols_of);
+    // adjacency lists in the reference's push_back order (:152-176): column order, source row then destination row
+    int64_t nrows = 0, nnz = 2 * (int64_t)cols_of.size();
+    for (int64_t g = 0; g < G; ++g) nrows += std::max<int64_t>(ptr[g + 1] - ptr[g], 0) + 1;
+    if (nnz >= (int64_t)INT32_MAX) return fail(UGS_E_UNSUPPORTED, "batch too large");
+    size_t off_desc = 0;
+    size_t off_row = align_up(off_desc + (size_t)std::max<int64_t>(G, 1) * sizeof(UgsGraphDesc));
+    size_t off_nbr = align_up(off_row + (size_t)std::max<int64_t>(nrows, 1) * sizeof(int64_t));
+    size_t off_ecs = align_up(off_nbr + (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t));
+    size_t total = align_up(off_ecs + (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t));
+    std::vector<char> host(total, 0);
+    auto *desc = reinterpret_cast<UgsGraphDesc *>(host.data() + off_desc);
+    auto *rowp = reinterpret_cast<int64_t *>(host.data() + off_row);
+    auto *nbr = reinterpret_cast<int32_t *>(host.data() + off_nbr);
+    auto *ecs = reinterpret_cast<int32_t *>(host.data() + off_ecs);
+    int64_t rb = 0, ab = 0;
+    std::vector<int64_t> wr;
+    for (int64_t g = 0; g < G; ++g) {
+        const int64_t lo = ptr[g], n = std::max<int64_t>(ptr[g + 1] - ptr[g], 0);
+        if (n >= (int64_t)INT32_MAX) return fail(UGS_E_UNSUPPORTED, "graph too large");
+        UgsGraphDesc &d = desc[g];
+        d.node_lo = lo; d.rbase = rb; d.vbase = 0; d.viable_base = 0; d.n = (int32_t)n; d.level = 0; d.n_viable = 0; d.pad = 0;
+        const int64_t c0 = cstart[(size_t)g], cn = cstart[(size_t)g + 1] - c0;
+        for (int64_t r = 0; r <= n; ++r) rowp[rb + r] = 0;
+        for (int64_t t = 0; t < cn; ++t) { const int64_t j = cols_of[(size_t)(c0 + t)]; ++rowp[rb + (src[j] - lo) + 1]; ++rowp[rb + (dst[j] - lo) + 1]; }
+        for (int64_t r = 0; r < n; ++r) rowp[rb + r + 1] += rowp[rb + r];
+        wr.assign(rowp + rb, rowp + rb + n);
+        for (int64_t t = 0; t < cn; ++t) {
+            const int64_t j = cols_of[(size_t)(c0 + t)], u = src[j] - lo, v = dst[j] - lo;
+            int64_t a = ab + wr[(size_t)u]++; nbr[a] = (int32_t)v; ecs[a] = (int32_t)(2 * j);
+            int64_t b = ab + wr[(size_t)v]++; nbr[b] = (int32_t)u; ecs[b] = (int32_t)(2 * j + 1);
+        }
+        for (int64_t r = 0; r <= n; ++r) rowp[rb + r] += ab;
+        rb += n + 1; ab += 2 * cn;
+    }
+    auto *j = new ugs_job();
+    j->dc = dc; j->eps = true; j->batch = true; j->m = m_per_graph; j->k = k; j->mode = mode; j->G = G;
+    j->rows = G * (int64_t)m_per_graph;
+    auto bail = [&](int rc) { free_job(j); return rc; };
+    hipError_t e = hipMalloc(&j->eps_blob, total);
+    if (e != hipSuccess) return bail(fail_hip(e, "hipMalloc"));
+    e = hipMemcpy(j->eps_blob, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bail(fail_hip(e, "hipMemcpy"));
+    char *base = static_cast<char *>(j->eps_blob);
+    if (int rc = pool_get((size_t)std::max<int64_t>(j->rows * k, 1) * sizeof(int64_t), dc.id, j->nodes)) return bail(rc);
+    if (int rc = pool_get((size_t)(j->rows + 1) * sizeof(int64_t), dc.id, j->eptr)) return bail(rc);
+    if (int rc = pool_get((size_t)std::max<int64_t>(j->rows, 1) * sizeof(uint32_t), dc.id, j->eps_counts)) return bail(rc);
+    if (int rc = pool_get((size_t)ugs_scan_tmp_words(j->rows) * sizeof(int64_t), dc.id, j->eps_scantmp)) return bail(rc);
+    UgsEpsLaunch &l = j->eps_l;
+    l.graphs = reinterpret_cast<const UgsGraphDesc *>(base + off_desc);
+    l.rowptr = reinterpret_cast<const int64_t *>(base + off_row);
+    l.nbr = reinterpret_cast<const int32_t *>(base + off_nbr);
+    l.ecs = reinterpret_cast<const int32_t *>(base + off_ecs);
+    l.num_graphs = G; l.m = m_per_graph; l.k = k; l.mode = mode;
+    l.max_attempts = std::max(10, (int)(10.0 / epsilon));
+    l.seed = seed; l.epsilon = epsilon; l.rows = j->rows;
+    l.nodes = static_cast<int64_t *>(j->nodes.p); l.counts = static_cast<uint32_t *>(j->eps_counts.p);
+    l.edge_ptr = nullptr; l.edge_index = nullptr; l.edge_src = nullptr; l.ld = 0;
+    e = ugs_eps_launch(l, 0, dc.cus, dc.stream);
+    if (e != hipSuccess) return bail(fail_hip(e, "ugs_eps_walk"));
+    e = ugs_launch_scan(l.counts, j->rows, static_cast<int64_t *>(j->eptr.p), static_cast<int64_t *>(j->eps_scantmp.p), dc.stream);
+    if (e != hipSuccess) return bail(fail_hip(e, "ugs_launch_scan"));
+    e = hipMemcpyAsync(&j->total, static_cast<int64_t *>(j->eptr.p) + j->rows, sizeof(int64_t), hipMemcpyDeviceToHost, dc.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(dc.stream);
+    if (e != hipSuccess) return bail(fail_hip(e, "epsilon walk"));
+    *job_out = j;
+    if (total_edges_out) *total_edges_out = j->total;
+    return UGS_OK;
+}
+
+int ugs_eps_sample_batch_finish(ugs_job *job, int64_t *nodes, int64_t *edge_index, int64_t *edge_ptr, int64_t *sample_ptr,
+                                int64_t *edge_src, int dst_is_device) {
+    if (!job || !job->eps) return fail(UGS_E_BAD_ARG, "not an epsilon job");
+    return finish_common(job, nodes, edge_index, edge_ptr, sample_ptr, edge_src, dst_is_device);
+}
 
 }  // extern "C"
