@@ -93,9 +93,9 @@ struct UgsLaunchInfo {
 };
 
 // tiers of the walk kernel: candidate-set capacity held in LDS per walk, lanes per walk
-enum { UGS_TIER_S = 0 /* cap 64, 8 lanes */, UGS_TIER_M = 1 /* cap 512, 64 lanes */, UGS_TIER_L = 2 /* cap 2048, 64 lanes */,
+enum { UGS_TIER_S = 0 /* cap 64, 8 lanes */, UGS_TIER_M = 1 /* cap 448, 64 lanes */, UGS_TIER_L = 2 /* cap 2048, 64 lanes */,
        UGS_TIER_G = 3 /* global-memory workspace, 64 lanes */ };
-static const int UGS_TIER_CAP[3] = {64, 512, 2048};
+static const int UGS_TIER_CAP[3] = {64, 448, 2048};
 
 hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int device_cus, hipStream_t s, UgsLaunchInfo *info);
 hipError_t ugs_launch_scan(const uint32_t *counts, int64_t rows, int64_t *edge_ptr, int64_t *block_tmp, hipStream_t s);

@@ -200,7 +200,7 @@ void weigh_roots(Graph &G, int k) {
 
 int make_graph(const int64_t *src, const int64_t *dst, int64_t E, int64_t n, int k, std::shared_ptr<Graph> &out) {
     if (n < 0) return fail(UGS_E_BAD_ARG, "num_nodes must be >= 0");
-    if (n >= (int64_t)INT32_MAX || E >= (int64_t)INT32_MAX) return fail(UGS_E_UNSUPPORTED, "graph too large: num_nodes and columns must be < 2^31 - 1");
+    if (n >= ((int64_t)1 << 30) - 1 || E >= (int64_t)INT32_MAX) return fail(UGS_E_UNSUPPORTED, "graph too large: num_nodes must be < 2^30 - 1 and columns < 2^31 - 1");
     auto G = std::make_shared<Graph>();
     G->n = n;
     G->k_built = k;

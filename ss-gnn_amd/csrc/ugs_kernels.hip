@@ -168,7 +168,7 @@ template <class SP> struct Work {
     uint32_t *ORD;           // materialised order of every non-final stage, stage i at ORD + d_chain.O[i]
     typename SP::TA *AUX;    // per element: position inside its bucket (generic path only)   [cap]
     typename SP::TW *TBL;    // per bucket: (round|pos) -> (size|first) -> start     [bcap]
-    uint32_t *HK, *HP;       // membership hash: key / (local index in sample | first-seen sequence number)  [hs]
+    uint32_t *HK;            // membership hash (open addressing): vertex id | kFresh | kInS               [hs]
     uint32_t cap, hmask, hlimit;
 };
 
@@ -478,9 +478,12 @@ template <int GS, int MAXPER> __device__ __forceinline__ uint32_t select_any(con
 //     the mirror entry in the earlier member's row; entries to itself count once),
 //   - ADD: appends neighbours that pass the suffix filter and were never seen to D (first-occurrence order).
 // Returns false when the walk outgrew this tier's workspace.
+// key word of the membership hash: vertex id (< 2^30) | kFresh (inserted by the chunk being processed) | kInS (sampled)
+constexpr uint32_t kKeyMask = 0x3FFFFFFFu, kFresh = 0x40000000u, kInS = 0x80000000u;
+
 template <int GS, class SP, bool ADD>
 __device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, const UgsPlanDev &P, int64_t rbase, uint32_t v,
-                                         uint32_t root_vi, uint32_t size, uint32_t &c, uint32_t &hcount, uint32_t &seq,
+                                         uint32_t root_vi, uint32_t size, uint32_t &c, uint32_t &hcount,
                                          uint32_t &ecount, int64_t r0, int64_t r1) {
     for (int64_t base = r0; base < r1; base += GS) {
         const int64_t p = base + g.lane;
@@ -491,43 +494,52 @@ __device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, c
             w = (uint32_t)e.x;
             cand = (uint32_t)e.y >= root_vi;
         }
-        uint32_t val = kEmpty;
         uint32_t slot = hash_slot(w, ws.hmask);
-        const uint32_t myseq = seq + g.lane;
+        bool in_s = false;
         if (ADD) {
             if (hcount + (uint32_t)__popcll(g.ballot(cand)) > ws.hlimit) return false;
+            bool inserted = false, fresh_dup = false;
             if (cand) {
-                for (uint32_t it = 0; it <= ws.hmask; ++it) {       // the table is never more than 3/4 full
-                    uint32_t old = atomicCAS(&ws.HK[slot], kEmpty, w);
-                    if (old == kEmpty || old == w) break;
+                for (uint32_t it = 0; it <= ws.hmask; ++it) {       // the table is never full
+                    const uint32_t old = atomicCAS(&ws.HK[slot], kEmpty, w | kFresh);
+                    if (old == kEmpty) { inserted = true; break; }
+                    if ((old & kKeyMask) == w) { in_s = (old & kInS) != 0u; fresh_dup = (old & kFresh) != 0u; break; }
                     slot = (slot + 1) & ws.hmask;
                 }
-                atomicMin(&ws.HP[slot], myseq);
             }
             SP::sync();
-            if (cand) val = ws.HP[slot];
-        } else {
-            if (cand) {
-                for (uint32_t it = 0; it <= ws.hmask; ++it) {
-                    uint32_t cur = ws.HK[slot];
-                    if (cur == w) { val = ws.HP[slot]; break; }
-                    if (cur == kEmpty) break;
-                    slot = (slot + 1) & ws.hmask;
-                }
+            // A vertex is NEW if this chunk inserted it; its place in D is that of its FIRST occurrence in the row.  Lanes
+            // that met a key inserted by this very chunk (a repeated neighbour, e.g. both directions of a PyG edge) are
+            // resolved per repeated vertex: the lowest lane holding it represents it.
+            bool first = inserted;
+            uint64_t dupm = g.ballot(fresh_dup);
+            while (dupm) {
+                const int li = __ffsll((long long)dupm) - 1;
+                const uint32_t wi = g.bcast(w, li);
+                const bool mine = cand && w == wi;
+                const uint64_t grp = g.ballot(mine);
+                if (mine) first = g.lane == (__ffsll((long long)grp) - 1);
+                dupm &= ~grp;
             }
-        }
-        // HP < UGS_KMAX: member of the sample, value = its local index
-        ecount += 2u * (uint32_t)__popcll(g.ballot(val < size - 1)) + (uint32_t)__popcll(g.ballot(val == size - 1));
-        if (ADD) {
-            const bool first = cand && val == myseq;
+            if (inserted) ws.HK[slot] = w;                            // the chunk is over for this key: drop kFresh
+            ecount += 2u * (uint32_t)__popcll(g.ballot(in_s && w != v)) + (uint32_t)__popcll(g.ballot(in_s && w == v));
             const uint64_t fm = g.ballot(first);
             const uint32_t nnew = (uint32_t)__popcll(fm);
             if (c + nnew > ws.cap) return false;
             if (first) ws.D[c + (uint32_t)__popcll(fm & g.lt_mask())] = w;
             c += nnew;
             hcount += nnew;
-            seq += GS;
             SP::sync();
+        } else {
+            if (cand) {
+                for (uint32_t it = 0; it <= ws.hmask; ++it) {
+                    const uint32_t cur = ws.HK[slot];
+                    if (cur == kEmpty) break;
+                    if ((cur & kKeyMask) == w) { in_s = (cur & kInS) != 0u; break; }
+                    slot = (slot + 1) & ws.hmask;
+                }
+            }
+            ecount += 2u * (uint32_t)__popcll(g.ballot(in_s && w != v)) + (uint32_t)__popcll(g.ballot(in_s && w == v));
         }
     }
     return true;
@@ -568,21 +580,21 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
         root_vi = (uint32_t)vr.x;
         root_v = (uint32_t)vr.y;
     }
-    // reset the membership hash (HK and HP are adjacent: 2 * slots words of 0xFFFFFFFF, 16 bytes per store)
+    // reset the membership hash (16 bytes per store)
     {
         uint4 *H4 = reinterpret_cast<uint4 *>(ws.HK);
-        const uint32_t n4 = (ws.hmask + 1u) >> 1;
+        const uint32_t n4 = (ws.hmask + 1u) >> 2;
         for (uint32_t s = g.lane; s < n4; s += GS) H4[s] = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
     }
     SP::sync();
-    if (g.lane == 0) { uint32_t s = hash_slot(root_v, ws.hmask); ws.HK[s] = root_v; ws.HP[s] = 0; SV[0] = root_v; }
+    if (g.lane == 0) { ws.HK[hash_slot(root_v, ws.hmask)] = root_v | kInS; SV[0] = root_v; }
     SP::sync();
-    uint32_t size = 1, c = 0, hcount = 1, seq = UGS_KMAX, ecount = 0;
+    uint32_t size = 1, c = 0, hcount = 1, ecount = 0;
     int nvalid = 0;           // leading stages of the order computation that are still valid
     STAMP_END(0);
     int64_t r0 = P.rowptr[gd.rbase + root_v], r1 = P.rowptr[gd.rbase + root_v + 1];
-    bool ok = (k > 1) ? scan_row<GS, SP, true>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, seq, ecount, r0, r1)
-                      : scan_row<GS, SP, false>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, seq, ecount, r0, r1);
+    bool ok = (k > 1) ? scan_row<GS, SP, true>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, ecount, r0, r1)
+                      : scan_row<GS, SP, false>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, ecount, r0, r1);
     STAMP_END(1);
     if (!ok) return false;
     for (int step = 1; step < k; ++step) {
@@ -623,14 +635,14 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
         if (g.lane == 0) {
             uint32_t s = hash_slot(w, ws.hmask);
             for (uint32_t it = 0; it <= ws.hmask && ws.HK[s] != w; ++it) s = (s + 1) & ws.hmask;
-            ws.HP[s] = size;          // local index in the sample
+            ws.HK[s] = w | kInS;      // now a member of the sample
             SV[size] = w;
         }
         size += 1;
         SP::sync();
         STAMP_END(3);
-        ok = (step < k - 1) ? scan_row<GS, SP, true>(ws, g, P, gd.rbase, w, root_vi, size, c, hcount, seq, ecount, r0, r1)
-                            : scan_row<GS, SP, false>(ws, g, P, gd.rbase, w, root_vi, size, c, hcount, seq, ecount, r0, r1);
+        ok = (step < k - 1) ? scan_row<GS, SP, true>(ws, g, P, gd.rbase, w, root_vi, size, c, hcount, ecount, r0, r1)
+                            : scan_row<GS, SP, false>(ws, g, P, gd.rbase, w, root_vi, size, c, hcount, ecount, r0, r1);
         STAMP_END(1);
         if (!ok) return false;
     }
@@ -651,7 +663,7 @@ template <int CAP> struct TierCfg {
     static constexpr int BCAP_A = (BCAP + 3) & ~3;
     static constexpr int HS = CAP <= 64 ? 128 : (CAP <= 512 ? 512 : 4096);
     static constexpr int HLIMIT = CAP <= 512 && CAP > 64 ? HS / 8 * 7 : HS / 4 * 3;   // max distinct vertices a walk may have seen
-    static constexpr int WORDS = CAP /*D*/ + ORDW + BCAP_A /*TBL*/ + 2 * HS /*HK,HP*/ + UGS_KMAX /*SV*/;
+    static constexpr int WORDS = CAP /*D*/ + ORDW + BCAP_A /*TBL*/ + HS /*HK*/ + UGS_KMAX /*SV*/;
 };
 
 template <int GS, int CAP, int BLOCK>
@@ -669,8 +681,7 @@ __global__ __launch_bounds__(BLOCK) void ugs_walk_lds(UgsWalkArgs a) {
     ws.AUX = nullptr;                      // the register-resident stages need no per-element scratch
     ws.TBL = ws.ORD + Cfg::ORDW;
     ws.HK = ws.TBL + Cfg::BCAP_A;
-    ws.HP = ws.HK + Cfg::HS;
-    uint32_t *SV = ws.HP + Cfg::HS;
+    uint32_t *SV = ws.HK + Cfg::HS;
     ws.cap = CAP;
     ws.hmask = Cfg::HS - 1;
     ws.hlimit = Cfg::HLIMIT;
@@ -697,7 +708,6 @@ __global__ __launch_bounds__(64) void ugs_walk_global(UgsWalkArgs a) {
     ws.ORD = ws.D + al4(a.gcap);
     ws.AUX = ws.ORD + al4(a.gpcap);                              // gpcap = words of all materialised stage orders
     ws.HK = ws.AUX + al4(a.gcap);
-    ws.HP = ws.HK + a.ghs;
     ws.cap = (uint32_t)a.gcap;
     ws.hmask = (uint32_t)a.ghs - 1u;
     ws.hlimit = (uint32_t)a.ghs / 4u * 3u;
@@ -889,7 +899,7 @@ int64_t ugs_scan_tmp_words(int64_t rows) { return (rows + kScanTile - 1) / kScan
 
 int64_t ugs_global_ws_words(int64_t gcap, int64_t gbcap, int64_t gpcap, int64_t ghs) {
     auto al4 = [](int64_t x) { return (x + 3) & ~3ll; };
-    return 2 * al4(gbcap) + al4(gcap) + al4(gpcap) + al4(gcap) + 2 * ghs;
+    return 2 * al4(gbcap) + al4(gcap) + al4(gpcap) + al4(gcap) + ghs;
 }
 
 int64_t ugs_ord_words(int stages) { return (int64_t)ord_words_before(stages); }   // words holding the orders of stages [0, stages)
@@ -919,7 +929,7 @@ hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, hipStream_t 
     if (cus <= 0) cus = 256;
     switch (tier) {
     case UGS_TIER_S: return launch_lds<8, 64, 256>(a, cus, 2, s, info, "ugs_walk_lds<8,64>");
-    case UGS_TIER_M: return launch_lds<64, 512, 64>(a, cus, 15, s, info, "ugs_walk_lds<64,512>");
+    case UGS_TIER_M: return launch_lds<64, 448, 64>(a, cus, 20, s, info, "ugs_walk_lds<64,448>");
     case UGS_TIER_L: return launch_lds<64, 2048, 64>(a, cus, 2, s, info, "ugs_walk_lds<64,2048>");
     default: {
         int64_t grid = a.gws_words_per_group > 0 ? a.gws_groups : 0;
