@@ -141,6 +141,16 @@ int ugs_eps_sample_batch_begin(const int64_t *edge_index, int64_t row_stride, in
 int ugs_eps_sample_batch_finish(ugs_job *job, int64_t *nodes, int64_t *edge_index, int64_t *edge_ptr, int64_t *sample_ptr,
                                 int64_t *edge_src, int dst_is_device);
 
+/* ---- apx_ugs_sampler.sample_batch(edge_index, ptr, m_per_graph, k, mode, seed, epsilon): replaces the reference's
+ *      src/samplers/apx_ugs_sampler/src/apx_ugs_sampler.cpp:461-519.  First graph only;
+ *      ptr[0]:ptr[1] is a range of edge COLUMNS (:15-33).  The reference draws everything from ONE sequential
+ *      std::mt19937_64 stream, which has no parallel bit-exact form: this entry point is a HOST computation that consumes the
+ *      same generator in the same order (bit-exact on the same toolchain).  It is not part of the GPU hot path.
+ *      samples_out: capacity m_per_graph * k int64, sample s at samples_out[s*k .. s*k+k); *num_samples_out = S <= m_per_graph
+ *      (failed samples are dropped, like the reference). */
+int ugs_apx_sample_batch(const int64_t *edge_index, int64_t row_stride, int64_t num_cols, const int64_t *ptr, int64_t ptr_len,
+                         int m_per_graph, int k, uint64_t seed, double epsilon, int64_t *samples_out, int64_t *num_samples_out);
+
 /* Per-kernel timing with HIP events recorded on the launch stream (off by default).  get_timing synchronises the
  * recorded events, returns summed milliseconds and launch counts for [0] the first-tier walk kernel, [1] overflow
  * tiers + scan kernels, [2] the fill kernel since the last call, and clears them. */

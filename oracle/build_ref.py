@@ -113,6 +113,49 @@ def load_eps():
     return mod
 
 
+APX_REF = "/root/reference/src/samplers/apx_ugs_sampler"
+APX_OUT = os.path.join(OUT_DIR, "apx_ugs_sampler" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_apx(force: bool = False) -> str:
+    """The reference apx_ugs_sampler module, compiled unmodified from its one source file (no deviation needed)."""
+    if not os.path.isdir(APX_REF):
+        raise FileNotFoundError(APX_REF)
+    src = os.path.join(APX_REF, "src", "apx_ugs_sampler.cpp")
+    hdr = os.path.join(APX_REF, "include", "apx_ugs_sampler.hpp")
+    if not force and os.path.exists(APX_OUT) and all(os.path.getmtime(APX_OUT) >= os.path.getmtime(x) for x in (src, hdr)):
+        return APX_OUT
+    import pybind11
+    import torch
+    from torch.utils import cpp_extension as ce
+
+    os.makedirs(OUT_DIR, exist_ok=True)
+    cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-w", "-fopenmp", "-DTORCH_EXTENSION_NAME=apx_ugs_sampler",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           f"-I{APX_REF}/include"]
+    for p in ce.include_paths():
+        cmd.append(f"-I{p}")
+    cmd += [f"-I{pybind11.get_include()}", f"-I{sysconfig.get_paths()['include']}", src, "-o", APX_OUT]
+    for p in ce.library_paths():
+        cmd += [f"-L{p}", f"-Wl,-rpath,{p}"]
+    cmd += ["-lc10", "-ltorch", "-ltorch_cpu", "-ltorch_python"]
+    subprocess.run(cmd, check=True)
+    return APX_OUT
+
+
+def load_apx():
+    import importlib.util
+
+    import torch  # noqa: F401
+
+    path = APX_OUT if os.path.exists(APX_OUT) else build_apx()
+    spec = importlib.util.spec_from_file_location("apx_ugs_sampler", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
     print(build_eps(force="--force" in sys.argv))
+    print(build_apx(force="--force" in sys.argv))
