@@ -313,8 +313,27 @@ def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
     for _ in range(reps):
         ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode="sample", seed=42)
     dt_host = (time.perf_counter() - t) / reps
+    # shuffled mini-batches: every call is a NEW combination of already-seen graphs (per-graph LRU hits, plan-cache miss)
+    rng = np.random.default_rng(0)
+    n_per = int(ptr[1] - ptr[0])
+    cols_per = ei.shape[1] // G
+    shuffled = []
+    for _ in range(min(reps, 20)):
+        perm = rng.permutation(G)
+        blocks = [ei[:, g * cols_per:(g + 1) * cols_per] - g * n_per + i * n_per for i, g in enumerate(perm)]
+        shuffled.append(torch.from_numpy(np.ascontiguousarray(np.concatenate(blocks, axis=1))))
+    t = time.perf_counter()
+    for e_s in shuffled:
+        ugs_sampler.sample_batch(e_s, ptr_t, m, k, mode="sample", seed=42)
+    dt_shuf = (time.perf_counter() - t) / len(shuffled)
+    t = time.perf_counter()
+    for _ in range(reps):
+        out_dev = ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode="sample", seed=42, device=dev)
+    torch.cuda.synchronize()
+    dt_devout = (time.perf_counter() - t) / reps
     res = {"rows": rows, "k": k, "device_resident_subgraphs_per_s": round(rows / dt_dev, 1), "device_resident_ms": round(dt_dev * 1e3, 4),
-           "drop_in_call_subgraphs_per_s": round(rows / dt_host, 1), "drop_in_call_ms": round(dt_host * 1e3, 4)}
+           "drop_in_call_subgraphs_per_s": round(rows / dt_host, 1), "drop_in_call_ms": round(dt_host * 1e3, 4),
+           "drop_in_call_shuffled_batch_ms": round(dt_shuf * 1e3, 4), "drop_in_call_device_out_ms": round(dt_devout * 1e3, 4)}
     try:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle

@@ -366,6 +366,7 @@ struct ugs_plan {
     int64_t G = 0, nverts = 0, nnz = 0;
     void *blob = nullptr;                 // one device allocation holding every array of the plan
     size_t blob_bytes = 0;
+    PoolBuf blob_buf;                     // small plans borrow their allocation from the scratch pool
     UgsPlanDev dev{};
     // per-graph statistics used to pick the walk tier for a given k
     std::vector<int64_t> g_n, g_maxdeg;
@@ -447,9 +448,14 @@ int assemble_plan(const std::vector<PlanPiece> &pieces, const DeviceCtx &dc, ugs
         rb += g.n + 1; vb += g.n; ab += g.nnz; if (g.level > 0) vib += (int64_t)g.viable.size();
     }
     void *dptr = nullptr;
-    HIP_TRY(hipMalloc(&dptr, total));
+    if (total <= ((size_t)64 << 20)) {      // batches of small graphs come and go with every shuffled mini-batch: pooled
+        if (int rc = pool_get(total, dc.id, plan->blob_buf)) return rc;
+        dptr = plan->blob_buf.p;
+    } else {
+        HIP_TRY(hipMalloc(&dptr, total));
+    }
     hipError_t e = hipMemcpy(dptr, host.data(), total, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(dptr); return fail_hip(e, "hipMemcpy(plan)"); }
+    if (e != hipSuccess) { if (plan->blob_buf.p) pool_put(plan->blob_buf); else (void)hipFree(dptr); return fail_hip(e, "hipMemcpy(plan)"); }
     plan->device = dc.id; plan->cus = dc.cus;
     plan->G = G; plan->nverts = nv; plan->nnz = nnz;
     plan->blob = dptr; plan->blob_bytes = total;
@@ -485,7 +491,7 @@ void ev_clear(ugs_plan *p) {
 void destroy_plan(ugs_plan *p) {
     if (!p) return;
     ev_clear(p);
-    if (p->blob) (void)hipFree(p->blob);
+    if (p->blob_buf.p) pool_put(p->blob_buf); else if (p->blob) (void)hipFree(p->blob);
     pool_put(p->counts); pool_put(p->ovf1); pool_put(p->ovf2); pool_put(p->ovfcnt); pool_put(p->scantmp);
     if (p->gws.p) { (void)hipFree(p->gws.p); p->gws = PoolBuf(); }
     delete p;

@@ -26,6 +26,7 @@
 //     free; root records pack the alias row and both candidate root vertices in 24 bytes.
 //   * ballot + popcount prefix sums compact new candidates into D and (fill kernel) edges into the output.
 #include "ugs_device.h"
+#include <cstdlib>
 
 #define UGS_ALIGNED16 __attribute__((aligned(16)))
 
@@ -123,6 +124,14 @@ template <int GS> struct Grp {
             x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
             x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
             x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+            return x;
+        }
+        if (GS == 32) {   // both 32-lane halves of the wave are active together (two walks per wave run in lock-step)
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
             return x;
         }
 #pragma unroll
@@ -444,8 +453,9 @@ __device__ __forceinline__ uint32_t select_lds(const Work<LdsSpace> &ws, const G
         else if (per <= 5) stage_mat<GS, 5>(ws, g, OLD, NEW, n_old, B, M, S);
         else if (per <= 9 || MAXPER <= 9) stage_mat<GS, 9>(ws, g, OLD, NEW, n_old, B, M, S);
         else if constexpr (MAXPER > 9) {
-            if (per <= 17) stage_mat<GS, 17>(ws, g, OLD, NEW, n_old, B, M, S);
-            else stage_mat<GS, 33>(ws, g, OLD, NEW, n_old, B, M, S);
+            if (per <= 13) stage_mat<GS, 13>(ws, g, OLD, NEW, n_old, B, M, S);
+            else if (per <= 17 || MAXPER <= 17) stage_mat<GS, 17>(ws, g, OLD, NEW, n_old, B, M, S);
+            else if constexpr (MAXPER > 17) stage_mat<GS, 33>(ws, g, OLD, NEW, n_old, B, M, S);
         }
         nvalid = stage + 1;
     }
@@ -457,10 +467,13 @@ __device__ __forceinline__ uint32_t select_lds(const Work<LdsSpace> &ws, const G
         if (per <= 1) return stage_final<GS, 1>(ws, g, OLD, n_old, c, B, M, S, rsel);
         else if (per <= 3) return stage_final<GS, 3>(ws, g, OLD, n_old, c, B, M, S, rsel);
         else if (per <= 5) return stage_final<GS, 5>(ws, g, OLD, n_old, c, B, M, S, rsel);
+        else if (per <= 7) return stage_final<GS, 7>(ws, g, OLD, n_old, c, B, M, S, rsel);
         else if (per <= 9 || MAXPER <= 9) return stage_final<GS, 9>(ws, g, OLD, n_old, c, B, M, S, rsel);
         else if constexpr (MAXPER > 9) {
-            if (per <= 17) return stage_final<GS, 17>(ws, g, OLD, n_old, c, B, M, S, rsel);
-            return stage_final<GS, 33>(ws, g, OLD, n_old, c, B, M, S, rsel);
+            if (per <= 11) return stage_final<GS, 11>(ws, g, OLD, n_old, c, B, M, S, rsel);
+            else if (per <= 13) return stage_final<GS, 13>(ws, g, OLD, n_old, c, B, M, S, rsel);
+            else if (per <= 17 || MAXPER <= 17) return stage_final<GS, 17>(ws, g, OLD, n_old, c, B, M, S, rsel);
+            else if constexpr (MAXPER > 17) return stage_final<GS, 33>(ws, g, OLD, n_old, c, B, M, S, rsel);
         }
     }
     return mine;
@@ -929,6 +942,7 @@ hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, hipStream_t 
     if (cus <= 0) cus = 256;
     switch (tier) {
     case UGS_TIER_S: return launch_lds<8, 64, 256>(a, cus, 2, s, info, "ugs_walk_lds<8,64>");
+    // one walk per wave: two walks per wave (GS 32) measured 26.4 ms vs 18.7 ms per 1M walks on C5 (two chunks per row)
     case UGS_TIER_M: return launch_lds<64, 448, 64>(a, cus, 20, s, info, "ugs_walk_lds<64,448>");
     case UGS_TIER_L: return launch_lds<64, 2048, 64>(a, cus, 2, s, info, "ugs_walk_lds<64,2048>");
     default: {
