@@ -159,9 +159,6 @@ template <int GS> struct Grp {
 // memory-space policies of the per-walk workspace --------------------------------------------------------------------
 struct LdsSpace {       // LDS: one wave's LDS operations are serviced in issue order; only the compiler must be fenced
     using TW = uint32_t; using TA = uint16_t;
-    static constexpr int SH = 16;
-    static constexpr TW PMASK = 0xFFFFu, FLAG = 0x80000000u;
-    static constexpr TA UNASSIGNED = 0xFFFFu;
     static __device__ __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 };
 struct GlbSpace {       // global-memory fallback: agent-scope fence between phases (rare, correctness-first tier)
@@ -440,8 +437,6 @@ template <int GS, int MAXPER>
 __device__ __forceinline__ uint32_t select_lds(const Work<LdsSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel, int &nvalid) {
     int fs = 0;
     while (fs < kChainLen - 1 && d_chain.B[fs] < c) ++fs;
-    bool have = false;
-    uint32_t mine = 0u;
     for (int stage = nvalid < fs ? nvalid : fs; stage < fs; ++stage) {      // stages that are materialised (and then cached)
         const uint32_t B = d_chain.B[stage], M = d_chain.M[stage], S = d_chain.S[stage];
         const uint32_t *OLD = stage ? ws.ORD + d_chain.O[stage - 1] : ws.D;
@@ -476,7 +471,7 @@ __device__ __forceinline__ uint32_t select_lds(const Work<LdsSpace> &ws, const G
             else if constexpr (MAXPER > 17) return stage_final<GS, 33>(ws, g, OLD, n_old, c, B, M, S, rsel);
         }
     }
-    return mine;
+    return 0u;
 }
 
 template <int GS, int MAXPER> __device__ __forceinline__ uint32_t select_any(const Work<LdsSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel, int &nvalid) {
