@@ -490,6 +490,7 @@ void ev_clear(ugs_plan *p) {
 
 void destroy_plan(ugs_plan *p) {
     if (!p) return;
+    if (p->device >= 0 && hipSetDevice(p->device) == hipSuccess) (void)hipDeviceSynchronize();   // kernels may still read the plan
     ev_clear(p);
     if (p->blob_buf.p) pool_put(p->blob_buf); else if (p->blob) (void)hipFree(p->blob);
     pool_put(p->counts); pool_put(p->ovf1); pool_put(p->ovf2); pool_put(p->ovfcnt); pool_put(p->scantmp);
@@ -814,7 +815,7 @@ int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
         if (int rc = ensure(plan->ovf1, (size_t)row_count * sizeof(int64_t), plan->device)) return rc;
         if (int rc = ensure(plan->ovf2, (size_t)row_count * sizeof(int64_t), plan->device)) return rc;
     }
-    HIP_TRY(hipMemsetAsync(plan->ovfcnt.p, 0, 4 * sizeof(uint32_t), s));
+    if (may_overflow) HIP_TRY(hipMemsetAsync(plan->ovfcnt.p, 0, 4 * sizeof(uint32_t), s));   // no tier of this plan can overflow otherwise
     uint32_t *cnt = static_cast<uint32_t *>(plan->ovfcnt.p);
     UgsWalkArgs a{};
     a.plan = plan->dev;
@@ -870,7 +871,7 @@ int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
         uint32_t h[4] = {0, 0, 0, 0};
         int64_t tot = 0;
         HIP_TRY(hipMemcpyAsync(&tot, d_edge_ptr + row_count, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(h, plan->ovfcnt.p, sizeof(h), hipMemcpyDeviceToHost, s));
+        if (may_overflow) HIP_TRY(hipMemcpyAsync(h, plan->ovfcnt.p, sizeof(h), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         *total_edges_host = tot;
         plan->last_overflow = h[0];

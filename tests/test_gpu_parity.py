@@ -275,3 +275,54 @@ def test_full_size_properties_er_proxy_and_c4():
         assert h(torch.cat([p[0] for p in parts])) == h(nodes) and h(torch.cat([p[1] for p in parts], dim=1)) == h(eidx)
         assert h(torch.cat([p[3] for p in parts])) == h(esrc)
         plan.close()
+
+
+def test_more_edge_cases_vs_oracle(product, orc):
+    """k at its maximum (32) on a dense graph, k=1, m=0, zero graphs, isolated vertices, a non-monotone ptr (overlapping
+    node ranges: every graph scans every column, like the reference), duplicated columns and self loops everywhere."""
+    rng = random.Random(77)
+    calls = []
+    n = 60
+    dense = np.array([(u, v) for u in range(n) for v in range(u + 1, n) if rng.random() < 0.5], dtype=np.int64).T.reshape(2, -1)
+    calls.append(dict(fn="sample_batch", edge_index=dense, ptr=np.array([0, n], dtype=np.int64), m=12, k=32, mode="graph", seed=42))
+    calls.append(dict(fn="sample_batch", edge_index=dense, ptr=np.array([0, n], dtype=np.int64), m=12, k=1, mode="sample", seed=42))
+    calls.append(dict(fn="sample_batch", edge_index=dense, ptr=np.array([0, n], dtype=np.int64), m=0, k=3, mode="sample", seed=42))
+    calls.append(dict(fn="sample_batch", edge_index=np.zeros((2, 0), np.int64), ptr=np.array([0], dtype=np.int64), m=4, k=3, mode="sample", seed=42))
+    iso = np.array([(0, 1), (1, 2), (5, 6)], dtype=np.int64).T.reshape(2, -1)          # vertices 3, 4, 7, 8 isolated
+    calls.append(dict(fn="sample_batch", edge_index=iso, ptr=np.array([0, 9], dtype=np.int64), m=30, k=3, mode="global", seed=5))
+    calls.append(dict(fn="sample_batch", edge_index=iso, ptr=np.array([0, 9], dtype=np.int64), m=30, k=2, mode="global", seed=5))
+    multi = np.array([(0, 1), (0, 1), (1, 0), (1, 1), (1, 2), (2, 2), (2, 3), (3, 0), (3, 0)], dtype=np.int64).T.reshape(2, -1)
+    calls.append(dict(fn="sample_batch", edge_index=multi, ptr=np.array([0, 4], dtype=np.int64), m=50, k=3, mode="sample", seed=9))
+    overl = np.array([(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 0), (1, 4)], dtype=np.int64).T.reshape(2, -1)
+    calls.append(dict(fn="sample_batch", edge_index=overl, ptr=np.array([2, 6, 0, 5], dtype=np.int64), m=9, k=3, mode="global", seed=3))
+    _same(calls, product, orc, "edge cases")
+
+
+def test_lru_eviction_with_small_cache_matches_oracle():
+    """UGS_CACHE_SIZE=2 (read once per process, like the reference): evictions and re-creations with another k must follow
+    the reference's LRU exactly.  Runs in a subprocess because the capacity is fixed at first use."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, random
+os.environ["UGS_CACHE_SIZE"] = "2"
+sys.path[:0] = [os.path.join(os.getcwd(), p) for p in ("tests", "oracle", "ss-gnn_amd")]
+import numpy as np
+import scenarios as sc
+from backends import ProductBackend, OracleBackend
+rng = random.Random(4)
+graphs = []
+for n in (7, 9, 11, 13):
+    e = [(u, v) for u in range(n) for v in range(u + 1, n) if rng.random() < 0.4]
+    graphs.append((n, np.array(e + [(v, u) for u, v in e], dtype=np.int64).T.reshape(2, -1)))
+calls = []
+for t in range(24):
+    n, ei = graphs[rng.randrange(4)]
+    calls.append(dict(fn="sample_batch", edge_index=ei, ptr=np.array([0, n], dtype=np.int64), m=20, k=rng.choice([3, 4, 5]), mode="sample", seed=42))
+got = sc.run_scenario(calls, ProductBackend())
+want = sc.run_scenario(calls, OracleBackend(cache_capacity=2))
+assert all(all(np.array_equal(a, b) for a, b in zip(g, w)) for g, w in zip(got, want))
+print("OK")
+'''
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=150)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
