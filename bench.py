@@ -275,6 +275,12 @@ def main():
             except Exception as e:   # noqa: BLE001
                 extras[name] = {"error": str(e)}
         out["other_workloads"] = extras
+        try:
+            pr = port_vs_reference_on_er_proxy(wl, torch)
+            if pr is not None:
+                out["cpu_baseline_calibration"] = pr
+        except Exception as e:   # noqa: BLE001
+            out["cpu_baseline_calibration"] = {"error": str(e)[:200]}
     sys.stdout.flush()
     emit(json.dumps(out))
     if world > 1 or args.force_collate:
@@ -347,8 +353,62 @@ def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
         res["bit_exact_vs_cpu"] = bool(all(np.array_equal(a.numpy(), b) for a, b in zip(g, o)))
     except Exception as e:   # noqa: BLE001
         res["cpu_port_error"] = str(e)
+    try:     # the reference C++ itself (oracle/_ref, prebuilt in the build container from /root/reference), if it travelled
+        ref = load_prebuilt_reference()
+        if ref is not None:
+            ref.sample_batch(ei_t, ptr_t, 1, k, "sample", 42)            # warm its preprocessing LRU
+            best = 1e9
+            for _ in range(3):
+                t = time.perf_counter()
+                r = ref.sample_batch(ei_t, ptr_t, m, k, "sample", 42)
+                best = min(best, time.perf_counter() - t)
+            g = ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode="sample", seed=42)
+            res["reference_cpp_subgraphs_per_s"] = round(rows / best, 1)
+            res["bit_exact_vs_reference_cpp"] = bool(all(torch.equal(a, b) for a, b in zip(g, r)))
+    except Exception as e:   # noqa: BLE001
+        res["reference_cpp_error"] = str(e)[:200]
     plan.close()
     return res
+
+
+def load_prebuilt_reference():
+    """oracle/_ref/ugs_sampler*.so if present (never built here: the reference sources do not exist on the GPU box)."""
+    import glob
+    import importlib.util
+    hits = glob.glob(os.path.join(ROOT, "oracle", "_ref", "ugs_sampler*.so"))
+    if not hits:
+        return None
+    import torch  # noqa: F401
+    spec = importlib.util.spec_from_file_location("ugs_sampler", hits[0])
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def port_vs_reference_on_er_proxy(wl, torch):
+    """ER proxy small enough for the reference's O(n^2) preprocessing (n = 100k, same degree law as C5): k-subgraphs/s of
+    the reference C++ and of the oracle port on the same rows -- how conservative the `port` CPU baseline is."""
+    ref = load_prebuilt_reference()
+    if ref is None:
+        return None
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    ei, ptr = wl.er_graph(100_000, 2_000_000, 0)
+    n, k, m = 100_000, 8, 20_000
+    ei_t = torch.from_numpy(ei)
+    h = ref.create_preproc(ei_t, n, k)
+    t = time.perf_counter()
+    r = ref.sample(h, m, k, "local", 0, 42)
+    t_ref = time.perf_counter() - t
+    ref.destroy_preproc(h)
+    P = oracle.Preproc(ei, n, k)
+    t = time.perf_counter()
+    o = P.sample(m, k, "local", 0, 42)
+    t_port = time.perf_counter() - t
+    same = bool(all(np.array_equal(a.numpy(), b) for a, b in zip(r, o)))
+    return {"graph": "ER n=100k, 2M columns, k=8, 20000 rows", "reference_cpp_subgraphs_per_s": round(m / t_ref, 1),
+            "port_subgraphs_per_s": round(m / t_port, 1), "port_over_reference": round(t_ref / t_port, 3), "identical_output": same}
 
 
 if __name__ == "__main__":
