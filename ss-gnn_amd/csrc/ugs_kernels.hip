@@ -674,8 +674,11 @@ template <int CAP> struct TierCfg {
     static constexpr int WORDS = CAP /*D*/ + ORDW + BCAP_A /*TBL*/ + HS /*HK*/ + UGS_KMAX /*SV*/;
 };
 
+// second launch-bounds argument = waves per SIMD the register allocation must allow.  CAP 448: 4 (<= 128 VGPRs, no spills;
+// 5 would fit the LDS footprint but spills 144 B/lane and measured 22.6 ms vs 18.3 ms per 1M walks on C5); the LDS admits 20 one-wave
+// blocks per CU for CAP 448 (5 per SIMD) and 2 four-wave blocks for CAP 64 (2 per SIMD)
 template <int GS, int CAP, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void ugs_walk_lds(UgsWalkArgs a) {
+__global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 4 : (CAP <= 64 ? 2 : 1)) void ugs_walk_lds(UgsWalkArgs a) {
     using Cfg = TierCfg<CAP>;
     constexpr int GROUPS = BLOCK / GS;
     __shared__ __attribute__((aligned(16))) uint32_t lds[GROUPS * Cfg::WORDS];
@@ -889,6 +892,39 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
         }
     }
 }
+
+#ifdef UGS_PROBE   // diagnostic build only: one kernel per hot routine, to read their instruction counts from the ISA
+template <int NJ> __global__ __launch_bounds__(64, 4) void probe_final(uint32_t *out, uint32_t c, uint32_t rsel, int fs) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[TierCfg<448>::WORDS];
+    Grp<64> g; g.init();
+    Work<LdsSpace> ws; ws.D = lds; ws.ORD = ws.D + 448; ws.AUX = nullptr; ws.TBL = ws.ORD + TierCfg<448>::ORDW; ws.HK = ws.TBL + TierCfg<448>::BCAP_A;
+    ws.cap = 448; ws.hmask = 511; ws.hlimit = 448;
+    out[threadIdx.x] = stage_final<64, NJ>(ws, g, ws.ORD + d_chain.O[fs - 1], d_chain.B[fs - 1], c, d_chain.B[fs], d_chain.M[fs], d_chain.S[fs], rsel);
+}
+template <int NJ> __global__ __launch_bounds__(64, 4) void probe_mat(uint32_t *out, int stage) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[TierCfg<448>::WORDS];
+    Grp<64> g; g.init();
+    Work<LdsSpace> ws; ws.D = lds; ws.ORD = ws.D + 448; ws.AUX = nullptr; ws.TBL = ws.ORD + TierCfg<448>::ORDW; ws.HK = ws.TBL + TierCfg<448>::BCAP_A;
+    ws.cap = 448; ws.hmask = 511; ws.hlimit = 448;
+    stage_mat<64, NJ>(ws, g, ws.ORD + d_chain.O[stage - 1], ws.ORD + d_chain.O[stage], d_chain.B[stage - 1], d_chain.B[stage], d_chain.M[stage], d_chain.S[stage]);
+    out[threadIdx.x] = ws.ORD[threadIdx.x];
+}
+__global__ __launch_bounds__(64, 4) void probe_scan_row(uint32_t *out, UgsPlanDev P, uint32_t v, uint32_t root_vi, int64_t r0, int64_t r1) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[TierCfg<448>::WORDS];
+    Grp<64> g; g.init();
+    Work<LdsSpace> ws; ws.D = lds; ws.ORD = ws.D + 448; ws.AUX = nullptr; ws.TBL = ws.ORD + TierCfg<448>::ORDW; ws.HK = ws.TBL + TierCfg<448>::BCAP_A;
+    ws.cap = 448; ws.hmask = 511; ws.hlimit = 448;
+    uint32_t c = 5, hcount = 6, ecount = 0;
+    bool ok = scan_row<64, LdsSpace, true>(ws, g, P, 0, v, root_vi, 3, c, hcount, ecount, r0, r1);
+    out[threadIdx.x] = c + hcount + ecount + (ok ? 1u : 0u);
+}
+template __global__ void probe_final<1>(uint32_t *, uint32_t, uint32_t, int);
+template __global__ void probe_final<3>(uint32_t *, uint32_t, uint32_t, int);
+template __global__ void probe_final<5>(uint32_t *, uint32_t, uint32_t, int);
+template __global__ void probe_mat<1>(uint32_t *, int);
+template __global__ void probe_mat<3>(uint32_t *, int);
+template __global__ void probe_mat<5>(uint32_t *, int);
+#endif
 
 }  // namespace
 
