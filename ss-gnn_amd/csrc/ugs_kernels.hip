@@ -446,6 +446,7 @@ __device__ __forceinline__ uint32_t select_lds(const Work<LdsSpace> &ws, const G
         if (per <= 1) stage_mat<GS, 1>(ws, g, OLD, NEW, n_old, B, M, S);
         else if (per <= 3) stage_mat<GS, 3>(ws, g, OLD, NEW, n_old, B, M, S);
         else if (per <= 5) stage_mat<GS, 5>(ws, g, OLD, NEW, n_old, B, M, S);
+        else if (per <= 7 || MAXPER <= 7) stage_mat<GS, 7>(ws, g, OLD, NEW, n_old, B, M, S);
         else if (per <= 9 || MAXPER <= 9) stage_mat<GS, 9>(ws, g, OLD, NEW, n_old, B, M, S);
         else if constexpr (MAXPER > 9) {
             if (per <= 13) stage_mat<GS, 13>(ws, g, OLD, NEW, n_old, B, M, S);
@@ -462,7 +463,7 @@ __device__ __forceinline__ uint32_t select_lds(const Work<LdsSpace> &ws, const G
         if (per <= 1) return stage_final<GS, 1>(ws, g, OLD, n_old, c, B, M, S, rsel);
         else if (per <= 3) return stage_final<GS, 3>(ws, g, OLD, n_old, c, B, M, S, rsel);
         else if (per <= 5) return stage_final<GS, 5>(ws, g, OLD, n_old, c, B, M, S, rsel);
-        else if (per <= 7) return stage_final<GS, 7>(ws, g, OLD, n_old, c, B, M, S, rsel);
+        else if (per <= 7 || MAXPER <= 7) return stage_final<GS, 7>(ws, g, OLD, n_old, c, B, M, S, rsel);
         else if (per <= 9 || MAXPER <= 9) return stage_final<GS, 9>(ws, g, OLD, n_old, c, B, M, S, rsel);
         else if constexpr (MAXPER > 9) {
             if (per <= 11) return stage_final<GS, 11>(ws, g, OLD, n_old, c, B, M, S, rsel);
