@@ -18,10 +18,13 @@
 //     rebuilt at every step.  That order is reproduced without any linked list: D keeps the distinct candidates in
 //     first-insertion order (incrementally: drop the chosen vertex, append the new vertex's unseen neighbours), and
 //     the container's order is a staged stable grouping computed data-parallel per stage of the bucket chain
-//     13 -> 29 -> 59 -> ... : "peel rounds" of one LDS atomicMax per element give every element its position inside
-//     its bucket and every bucket its size and first element; a group-wide suffix scan of the bucket sizes gives each
-//     bucket's start; rank = start + position.  Only the last stage needs no materialisation: the lane whose rank
-//     equals rng % |cut| holds the answer.
+//     13 -> 29 -> 59 -> ... with every element in registers: atomicMin + atomicAdd on one LDS word per bucket give its
+//     first arrival and size, one DPP wave scan of the sizes over the bucket leaders gives every bucket's start, an
+//     atomicAdd-with-return hands out arrival slots into tiny per-bucket position lists from which every element counts
+//     the members above it; rank = start + count (stage_mat).  Every stage keeps its own order array, valid across
+//     growth steps while the removed candidate lies behind the prefix it covers.  The last stage materialises nothing:
+//     the bucket holding position rng % |cut| is found by the scan and the element inside it by ballots (stage_final).
+//     (The global-memory fallback tier keeps the simpler "peel round" formulation, select_in_order.)
 //   * the neighbour's order rank is stored next to the neighbour id in HBM (int2 adjacency), so the suffix filter is
 //     free; root records pack the alias row and both candidate root vertices in 24 bytes.
 //   * ballot + popcount prefix sums compact new candidates into D and (fill kernel) edges into the output.
