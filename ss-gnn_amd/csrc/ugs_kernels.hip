@@ -510,15 +510,19 @@ __device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, c
         bool in_s = false;
         if (ADD) {
             if (hcount + (uint32_t)__popcll(g.ballot(cand)) > ws.hlimit) return false;
-            bool inserted = false, fresh_dup = false;
+            // probe: only `seen` and `slot` are carried round the loop; what happened is read off `seen` afterwards
+            uint32_t seen = kKeyMask;                                 // a value no probe returns for a candidate
             if (cand) {
-                for (uint32_t it = 0; it <= ws.hmask; ++it) {       // the table is never full
-                    const uint32_t old = atomicCAS(&ws.HK[slot], kEmpty, w | kFresh);
-                    if (old == kEmpty) { inserted = true; break; }
-                    if ((old & kKeyMask) == w) { in_s = (old & kInS) != 0u; fresh_dup = (old & kFresh) != 0u; break; }
+                for (uint32_t it = 0; it <= ws.hmask; ++it) {         // the table is never full
+                    seen = atomicCAS(&ws.HK[slot], kEmpty, w | kFresh);
+                    if (seen == kEmpty || (seen & kKeyMask) == w) break;
                     slot = (slot + 1) & ws.hmask;
                 }
             }
+            const bool inserted = cand && seen == kEmpty;
+            const bool found = cand && seen != kEmpty && (seen & kKeyMask) == w;
+            in_s = found && (seen & kInS) != 0u;
+            const bool fresh_dup = found && (seen & kFresh) != 0u;
             SP::sync();
             // A vertex is NEW if this chunk inserted it; its place in D is that of its FIRST occurrence in the row.  Lanes
             // that met a key inserted by this very chunk (a repeated neighbour, e.g. both directions of a PyG edge) are
@@ -543,14 +547,15 @@ __device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, c
             hcount += nnew;
             SP::sync();
         } else {
+            uint32_t seen = kEmpty;
             if (cand) {
                 for (uint32_t it = 0; it <= ws.hmask; ++it) {
-                    const uint32_t cur = ws.HK[slot];
-                    if (cur == kEmpty) break;
-                    if ((cur & kKeyMask) == w) { in_s = (cur & kInS) != 0u; break; }
+                    seen = ws.HK[slot];
+                    if (seen == kEmpty || (seen & kKeyMask) == w) break;
                     slot = (slot + 1) & ws.hmask;
                 }
             }
+            in_s = cand && seen != kEmpty && (seen & kKeyMask) == w && (seen & kInS) != 0u;
             ecount += 2u * (uint32_t)__popcll(g.ballot(in_s && w != v)) + (uint32_t)__popcll(g.ballot(in_s && w == v));
         }
     }
