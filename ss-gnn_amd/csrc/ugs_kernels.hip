@@ -116,7 +116,12 @@ template <int GS> struct Grp {
     }
     __device__ __forceinline__ bool any(bool p) const { return ballot(p) != 0ull; }
     __device__ __forceinline__ uint64_t lt_mask() const { return (1ull << lane) - 1ull; }
-    template <class T> __device__ __forceinline__ T bcast(T v, int src) const { return __shfl(v, gbase + src, 64); }
+    // value of lane `src` of the group.  One walk per wave: `src` is wave-uniform, so v_readlane puts the result in a scalar
+    // register and everything derived from it (row bounds, loop limits, hash slot of the chosen vertex) stays scalar.
+    __device__ __forceinline__ uint32_t bcast(uint32_t v, int src) const {
+        if (GS == 64) return (uint32_t)__builtin_amdgcn_readlane((int)v, src);
+        return __shfl(v, gbase + src, 64);
+    }
     // inclusive prefix sum over the group's lanes (sum of x over lanes <= lane).  GS == 64: the whole wave is active
     // here, so the DPP row-shift / row-broadcast scan is used (6 VALU ops, no LDS crossbar traffic).
     __device__ __forceinline__ uint32_t prefix_incl(uint32_t x) const {
@@ -143,6 +148,14 @@ template <int GS> struct Grp {
             if (lane >= d) x += y;
         }
         return x;
+    }
+    // group-uniform values: with one walk per wave they are wave-uniform and belong in scalar registers
+    __device__ __forceinline__ uint32_t uni(uint32_t x) const { return GS == 64 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)x) : x; }
+    __device__ __forceinline__ int64_t uni(int64_t x) const {
+        if (GS != 64) return x;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)x >> 32));
+        return (int64_t)(((uint64_t)hi << 32) | lo);
     }
     __device__ __forceinline__ uint32_t last(uint32_t incl) const {      // value held by the group's last lane
         if (GS == 64) return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -589,13 +602,13 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
         double u = (double)rng.next() * 0x1p-64;   // == / (double)UINT64_MAX (which is 2^64): exact scaling
         const UgsRootRec rr = P.roots[gd.vbase + j];
         const bool self = u < rr.prob;
-        root_vi = self ? j : (uint32_t)rr.alias;
-        root_v = (uint32_t)(self ? rr.v_self : rr.v_alias);
+        root_vi = g.uni(self ? j : (uint32_t)rr.alias);
+        root_v = g.uni((uint32_t)(self ? rr.v_self : rr.v_alias));
     } else {                  // relaxed: uniform over the viable list, one number (reference src/sampler.cpp:169-172)
         uint32_t idx = (uint32_t)(rng.next() % (uint64_t)(uint32_t)gd.n_viable);
         int2 vr = P.viable[gd.viable_base + idx];
-        root_vi = (uint32_t)vr.x;
-        root_v = (uint32_t)vr.y;
+        root_vi = g.uni((uint32_t)vr.x);
+        root_v = g.uni((uint32_t)vr.y);
     }
     // reset the membership hash (16 bytes per store)
     {
@@ -609,18 +622,19 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
     uint32_t size = 1, c = 0, hcount = 1, ecount = 0;
     int nvalid = 0;           // leading stages of the order computation that are still valid
     STAMP_END(0);
-    int64_t r0 = P.rowptr[gd.rbase + root_v], r1 = P.rowptr[gd.rbase + root_v + 1];
+    int64_t r0 = g.uni(P.rowptr[gd.rbase + root_v]), r1 = g.uni(P.rowptr[gd.rbase + root_v + 1]);
     bool ok = (k > 1) ? scan_row<GS, SP, true>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, ecount, r0, r1)
                       : scan_row<GS, SP, false>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, ecount, r0, r1);
     STAMP_END(1);
     if (!ok) return false;
     for (int step = 1; step < k; ++step) {
         if (c == 0) break;                                                    // growth failed: partial row
-        const uint32_t rsel = (uint32_t)(rng.next() % (uint64_t)c);
+        const uint32_t rsel = g.uni((uint32_t)(rng.next() % (uint64_t)c));
         STAMP_END(4);
         const uint32_t w = select_any<GS, MAXPER>(ws, g, c, rsel, nvalid);
         r0 = P.rowptr[gd.rbase + w];               // issued now, consumed after the candidate list has been updated
         r1 = P.rowptr[gd.rbase + w + 1];
+        r0 = g.uni(r0); r1 = g.uni(r1);
         STAMP_END(2);
         // move w from the candidates to the sample: drop it from D keeping the order of the others
         uint32_t q = c;
