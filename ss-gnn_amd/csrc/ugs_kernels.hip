@@ -697,8 +697,11 @@ template <int CAP> struct TierCfg {
     static constexpr int WORDS = CAP /*D*/ + ORDW + BCAP_A /*TBL*/ + HS /*HK*/ + UGS_KMAX /*SV*/;
 };
 
-// second launch-bounds argument = waves per SIMD the register allocation must allow.  CAP 448: 4 (<= 128 VGPRs, no spills;
-// 5 would fit the LDS footprint but spills 144 B/lane and measured 22.6 ms vs 18.3 ms per 1M walks on C5); the LDS admits 20 one-wave
+// second launch-bounds argument = waves per SIMD the register allocation must allow.  CAP 448: 4 (<= 128 VGPRs, no spills).
+// Measured on C5 (same-box A/B, census build for residency): the LDS is granted in 1280-byte granules, so 8112 B/walk
+// admits 18 one-wave blocks per CU; a grid larger than the resident set runs in two uneven rounds (20/CU: +25 % time);
+// 3 waves/SIMD: 16.9 ms, 4: 13.6 ms; a leaner build (73 VGPRs, CAP 320, 20 resident waves/CU) is SLOWER (14.3 ms): the
+// CU is throughput-bound (issue + LDS) at ~16 waves, so occupancy is not a lever any more.  The LDS admits 20 one-wave
 // blocks per CU for CAP 448 (5 per SIMD) and 2 four-wave blocks for CAP 64 (2 per SIMD)
 template <int GS, int CAP, int BLOCK>
 __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 4 : (CAP <= 64 ? 2 : 1)) void ugs_walk_lds(UgsWalkArgs a) {
