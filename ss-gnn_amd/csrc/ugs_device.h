@@ -8,8 +8,9 @@
 //                                    (reference src/preproc.cpp:32-86).  rank(w) = index_of[w] is stored NEXT TO
 //                                    the neighbour so the suffix filter `index_of[w] >= root_vi`
 //                                    (reference src/sampler.cpp:62) costs no second (random) gather.
-//   ecol    int32[nnz]               value written to edge_src for this CSR entry (batch: column of the batch
-//                                    edge_index; handle API: column of the graph's edge_index)
+//   adjf    int2[nnz]                (w, ecol): the fill kernel's view of the same CSR -- neighbour and the value written to
+//                                    edge_src for this entry (batch: column of the batch edge_index; handle API: column
+//                                    of the graph's edge_index) side by side, so the edge column costs no extra gather
 //   roots   UgsRootRec[sum(n_g)]     alias table row + both candidate root vertices in ONE 24-byte record, so the
 //                                    root draw (reference include/sampler.hpp:72-77 + src/sampler.cpp:165-173) is one gather
 //   viable  int2[...]                (vi, order[vi]) lists for relaxation levels 1/2 (reference src/sampler.cpp:121-150)
@@ -42,7 +43,7 @@ struct UgsPlanDev {
     const UgsGraphDesc *graphs;
     const int64_t *rowptr;
     const int2 *adj;
-    const int32_t *ecol;
+    const int2 *adjf;
     const UgsRootRec *roots;
     const int2 *viable;
     int64_t num_graphs;

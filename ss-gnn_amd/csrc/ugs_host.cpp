@@ -410,14 +410,14 @@ int assemble_plan(const std::vector<PlanPiece> &pieces, const DeviceCtx &dc, ugs
     size_t off_row = align_up(off_desc + (size_t)std::max<int64_t>(G, 1) * sizeof(UgsGraphDesc));
     size_t off_adj = align_up(off_row + (size_t)std::max<int64_t>(nrows, 1) * sizeof(int64_t));
     size_t off_col = align_up(off_adj + (size_t)std::max<int64_t>(nnz, 1) * sizeof(int2));
-    size_t off_root = align_up(off_col + (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t));
+    size_t off_root = align_up(off_col + (size_t)std::max<int64_t>(nnz, 1) * sizeof(int2));
     size_t off_via = align_up(off_root + (size_t)std::max<int64_t>(nv, 1) * sizeof(UgsRootRec));
     size_t total = align_up(off_via + (size_t)std::max<int64_t>(nviable, 1) * sizeof(int2));
     std::vector<char> host(total, 0);
     auto *desc = reinterpret_cast<UgsGraphDesc *>(host.data() + off_desc);
     auto *rowp = reinterpret_cast<int64_t *>(host.data() + off_row);
     auto *adj = reinterpret_cast<int2 *>(host.data() + off_adj);
-    auto *ecol = reinterpret_cast<int32_t *>(host.data() + off_col);
+    auto *adjf = reinterpret_cast<int2 *>(host.data() + off_col);
     auto *roots = reinterpret_cast<UgsRootRec *>(host.data() + off_root);
     auto *via = reinterpret_cast<int2 *>(host.data() + off_via);
     int64_t rb = 0, vb = 0, ab = 0, vib = 0;
@@ -435,7 +435,7 @@ int assemble_plan(const std::vector<PlanPiece> &pieces, const DeviceCtx &dc, ugs
             const int32_t w = g.nbr[(size_t)p];
             adj[ab + p] = make_int2(w, g.rank[(size_t)w]);
             const int32_t c = g.col[(size_t)p];
-            ecol[ab + p] = pc.colmap ? (int32_t)pc.colmap[c] : c;
+            adjf[ab + p] = make_int2(w, pc.colmap ? (int32_t)pc.colmap[c] : c);
         }
         if (g.level == 0)
             for (int64_t vi = 0; vi < g.n; ++vi) {
@@ -463,7 +463,7 @@ int assemble_plan(const std::vector<PlanPiece> &pieces, const DeviceCtx &dc, ugs
     plan->dev.graphs = reinterpret_cast<const UgsGraphDesc *>(base + off_desc);
     plan->dev.rowptr = reinterpret_cast<const int64_t *>(base + off_row);
     plan->dev.adj = reinterpret_cast<const int2 *>(base + off_adj);
-    plan->dev.ecol = reinterpret_cast<const int32_t *>(base + off_col);
+    plan->dev.adjf = reinterpret_cast<const int2 *>(base + off_col);
     plan->dev.roots = reinterpret_cast<const UgsRootRec *>(base + off_root);
     plan->dev.viable = reinterpret_cast<const int2 *>(base + off_via);
     plan->dev.num_graphs = G;

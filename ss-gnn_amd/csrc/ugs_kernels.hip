@@ -880,20 +880,69 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
         LdsSpace::sync();
         const uint32_t T = PS[k];
         int64_t w_off = e0;
+        if (k <= 8) {
+            // the per-row prefix and vertex lists fit in registers: membership and row lookup are compares on registers
+            uint32_t ps[9], sv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { sv[t] = (t < k) ? SV[t] : 0xFFFFFFFEu /* matches no vertex and no idle lane */; ps[t] = (t < k) ? PS[t] : 0xFFFFFFFFu; }
+            ps[8] = 0xFFFFFFFFu;
+            for (uint32_t cb = 0; cb < T; cb += 4 * GS) {
+                uint32_t wv[4];
+                int jj[4], ec[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t e = cb + u * GS + g.lane;
+                    wv[u] = kEmpty; jj[u] = 0; ec[u] = 0;
+                    if (e < T) {
+                        int j = 0;
+#pragma unroll
+                        for (int t = 1; t < 8; ++t) j += (ps[t] <= e) ? 1 : 0;           // row of flattened entry e
+                        uint32_t base_e = ps[0];
+#pragma unroll
+                        for (int t = 1; t < 8; ++t) base_e = (j == t) ? ps[t] : base_e;
+                        jj[u] = j;
+                        const int2 nb = P.adjf[R0[j] + (int64_t)(e - base_e)];          // neighbour and its edge column together
+                        wv[u] = (uint32_t)nb.x;
+                        ec[u] = nb.y;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (cb + u * GS >= T) break;
+                    int l = -1;
+#pragma unroll
+                    for (int t = 7; t >= 0; --t) l = (sv[t] == wv[u]) ? t : l;
+                    const uint64_t mk = g.ballot(l >= 0);
+                    if (l >= 0) {
+                        const int64_t pos = w_off + __popcll(mk & g.lt_mask());
+                        const int j = jj[u];
+                        int64_t uf, vf;
+                        if (a.mode == 0) { uf = j; vf = l; }
+                        else if (a.mode == 1) { uf = i * k + j; vf = i * k + l; }
+                        else { uf = nrow[j]; vf = nrow[l]; }
+                        a.edge_index[pos] = uf;
+                        a.edge_index[a.ld + pos] = vf;
+                        a.edge_src[pos] = (int64_t)ec[u];
+                    }
+                    w_off += __popcll(mk);
+                }
+            }
+            continue;
+        }
         for (uint32_t cb = 0; cb < T; cb += 4 * GS) {
             uint32_t wv[4];
-            int jj[4];
-            int64_t pp[4];
+            int jj[4], ec[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t e = cb + u * GS + g.lane;
-                wv[u] = kEmpty; jj[u] = 0; pp[u] = 0;
+                wv[u] = kEmpty; jj[u] = 0; ec[u] = 0;
                 if (e < T) {
                     int j = 0;
                     for (int t = 1; t < k; ++t) j += (PS[t] <= e) ? 1 : 0;       // row of flattened entry e
                     jj[u] = j;
-                    pp[u] = R0[j] + (int64_t)(e - PS[j]);
-                    wv[u] = (uint32_t)P.adj[pp[u]].x;
+                    const int2 nb = P.adjf[R0[j] + (int64_t)(e - PS[j])];
+                    wv[u] = (uint32_t)nb.x;
+                    ec[u] = nb.y;
                 }
             }
 #pragma unroll
@@ -911,7 +960,7 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
                     else { uf = nrow[j]; vf = nrow[l]; }
                     a.edge_index[pos] = uf;
                     a.edge_index[a.ld + pos] = vf;
-                    a.edge_src[pos] = (int64_t)P.ecol[pp[u]];
+                    a.edge_src[pos] = (int64_t)ec[u];
                 }
                 w_off += __popcll(mk);
             }
