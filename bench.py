@@ -276,6 +276,10 @@ def main():
                 extras[name] = {"error": str(e)}
         out["other_workloads"] = extras
         try:
+            out["epsilon_uniform_sampler"] = bench_epsilon(wl, torch)
+        except Exception as e:   # noqa: BLE001
+            out["epsilon_uniform_sampler"] = {"error": str(e)[:200]}
+        try:
             pr = port_vs_reference_on_er_proxy(wl, torch)
             if pr is not None:
                 out["cpu_baseline_calibration"] = pr
@@ -368,6 +372,37 @@ def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
     except Exception as e:   # noqa: BLE001
         res["reference_cpp_error"] = str(e)[:200]
     plan.close()
+    return res
+
+
+def bench_epsilon(wl, torch, reps=20):
+    """epsilon_uniform_sampler.sample_batch on the PROTEINS-shaped batch (k=6, 32 x 256 samples, eps 0.1): the HIP entry
+    point (host tensors in and out) next to the reference module, if its prebuilt copy travelled (oracle/_ref)."""
+    import glob
+    import importlib.util
+    import epsilon_uniform_sampler as eps
+    ei, ptr, m, k = wl.workload("c3_proteins_b8192")
+    ei_t, ptr_t = torch.from_numpy(ei), torch.from_numpy(ptr)
+    rows = (len(ptr) - 1) * m
+    for _ in range(3):
+        o = eps.sample_batch(ei_t, ptr_t, m, k, "sample", 42, 0.1)
+    t = time.perf_counter()
+    for r in range(reps):
+        o = eps.sample_batch(ei_t, ptr_t, m, k, "sample", 42 + r, 0.1)
+    dt = (time.perf_counter() - t) / reps
+    res = {"rows": rows, "k": k, "epsilon": 0.1, "hip_call_ms": round(dt * 1e3, 4), "hip_subgraphs_per_s": round(rows / dt, 1),
+           "failed_rows": int((o[0][:, 0] < 0).sum())}
+    hits = glob.glob(os.path.join(ROOT, "oracle", "_ref", "epsilon_uniform_sampler*.so"))
+    if hits:
+        spec = importlib.util.spec_from_file_location("epsilon_uniform_sampler", hits[0])
+        ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref)
+        t = time.perf_counter()
+        r = ref.sample_batch(ei_t, ptr_t, m, k, "sample", 42, 0.1)
+        dt_ref = time.perf_counter() - t
+        res["reference_cpp_call_ms"] = round(dt_ref * 1e3, 3)
+        res["reference_cpp_subgraphs_per_s"] = round(rows / dt_ref, 1)
+        res["reference_threads"] = os.cpu_count()
     return res
 
 
