@@ -35,6 +35,14 @@ struct UgsEpsLaunch {
 };
 hipError_t ugs_eps_launch(const UgsEpsLaunch &l, int fill, int cus, hipStream_t s);
 
+// device-side preprocessing stages (ugs_preproc.hip)
+struct UgsDevPre;
+size_t ugs_devpre_bytes(int64_t n, int64_t E);
+hipError_t ugs_devpre_csr(UgsDevPre **out, const int64_t *h_src, const int64_t *h_dst, int64_t E, int64_t n, hipStream_t s, int64_t *h_rowptr, int64_t *nnz_out);
+hipError_t ugs_devpre_roots(UgsDevPre *d, const int32_t *h_order, const int32_t *h_rank, int k, int32_t *h_sdeg, uint8_t *h_reach);
+hipError_t ugs_devpre_download(UgsDevPre *d, int32_t *h_nbr, int32_t *h_col);
+void ugs_devpre_free(UgsDevPre *d);
+
 namespace {
 
 thread_local std::string t_err;
@@ -54,6 +62,7 @@ struct Graph {
     std::vector<int32_t> nbr, col;    // CSR neighbours and source column of each entry
     std::vector<int32_t> order, rank; // order[vi] = vertex, rank[vertex] = vi
     std::vector<int32_t> sdeg;        // suffix degree per order position
+    std::vector<uint8_t> reach;       // scratch: root reaches k vertices inside its suffix graph
     std::vector<double> weight;       // bucket weight per order position
     std::vector<double> prob;         // alias table (only if Z > 0)
     std::vector<int32_t> alias;
@@ -149,8 +158,8 @@ void build_alias(Graph &G) {
     for (int32_t i : lo) G.prob[(size_t)i] = 1.0;
 }
 
-// suffix degrees, k-reachability of every root inside its suffix graph, bucket weights d^(k-1), Z, alias table.
-void weigh_roots(Graph &G, int k) {
+// suffix degrees and k-reachability of every root inside its suffix graph (host form; ugs_preproc.hip is the device form)
+void root_stats_host(Graph &G, int k) {
     const int n = (int)G.n;
     G.sdeg.assign((size_t)n, 0);
     for (int vi = 0; vi < n; ++vi) {
@@ -159,9 +168,7 @@ void weigh_roots(Graph &G, int k) {
         for (int64_t p = G.rowptr[(size_t)v]; p < G.rowptr[(size_t)v + 1]; ++p) c += G.rank[(size_t)G.nbr[(size_t)p]] >= vi;
         G.sdeg[(size_t)vi] = c;
     }
-    G.weight.assign((size_t)n, 0.0);
-    G.Z = 0.0;
-    G.nonzero = 0;
+    G.reach.assign((size_t)n, 0);
     std::vector<int32_t> mark((size_t)n, -1), reached;
     reached.reserve((size_t)std::max(k, 1) + 1);
     for (int vi = 0; vi < n; ++vi) {
@@ -177,7 +184,18 @@ void weigh_roots(Graph &G, int k) {
                 reached.push_back(w);
             }
         }
-        if ((int)reached.size() >= k) {
+        G.reach[(size_t)vi] = (int)reached.size() >= k;
+    }
+}
+
+// bucket weights d^(k-1), Z (summed in order position order: the floating-point result depends on it), alias table
+void weigh_roots(Graph &G, int k) {
+    const int n = (int)G.n;
+    G.weight.assign((size_t)n, 0.0);
+    G.Z = 0.0;
+    G.nonzero = 0;
+    for (int vi = 0; vi < n; ++vi) {
+        if (G.reach[(size_t)vi]) {
             const double d = (double)std::max<int32_t>(1, G.sdeg[(size_t)vi]);
             double b = 1.0;
             for (int t = 1; t < k; ++t) b *= d;
@@ -186,6 +204,7 @@ void weigh_roots(Graph &G, int k) {
             if (b > 0.0) ++G.nonzero;
         }
     }
+    std::vector<uint8_t>().swap(G.reach);
     if (G.Z > 0.0) build_alias(G); else { G.prob.assign((size_t)n, 0.0); G.alias.assign((size_t)n, 0); }
     // relaxation levels of the root draw
     G.viable.clear();
@@ -198,15 +217,22 @@ void weigh_roots(Graph &G, int k) {
     if (debug_on()) std::fprintf(stderr, "[UGS PREPROC] n=%d k=%d Z=%.2e viable=%d/%d\n", n, k, G.Z, G.nonzero, n);
 }
 
+int preprocess_on_device(Graph &G, const int64_t *src, const int64_t *dst, int64_t E, int k, bool &done);   // below, after the device helpers
+
 int make_graph(const int64_t *src, const int64_t *dst, int64_t E, int64_t n, int k, std::shared_ptr<Graph> &out) {
     if (n < 0) return fail(UGS_E_BAD_ARG, "num_nodes must be >= 0");
     if (n >= ((int64_t)1 << 30) - 1 || E >= (int64_t)INT32_MAX) return fail(UGS_E_UNSUPPORTED, "graph too large: num_nodes must be < 2^30 - 1 and columns < 2^31 - 1");
     auto G = std::make_shared<Graph>();
     G->n = n;
     G->k_built = k;
-    build_adjacency(*G, src, dst, E);
-    if (G->nnz >= (int64_t)INT32_MAX) return fail(UGS_E_UNSUPPORTED, "graph too large: CSR entries must be < 2^31 - 1");
-    order_by_degree(*G);
+    bool on_device = false;
+    if (int rc = preprocess_on_device(*G, src, dst, E, k, on_device)) return rc;
+    if (!on_device) {
+        build_adjacency(*G, src, dst, E);
+        if (G->nnz >= (int64_t)INT32_MAX) return fail(UGS_E_UNSUPPORTED, "graph too large: CSR entries must be < 2^31 - 1");
+        order_by_degree(*G);
+        root_stats_host(*G, k);
+    }
     weigh_roots(*G, k);
     out = std::move(G);
     return UGS_OK;
@@ -400,6 +426,40 @@ struct PlanPiece {                 // one graph of a plan
 };
 
 size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Large graphs: the O(nnz) preprocessing stages on the GPU (ugs_preproc.hip).  The degree order stays on
+// the host (O(n)); the outcome is bit-identical to the host path.  UGS_DEVICE_PREPROC=0 never, =1 always (testing aid);
+// by default graphs with >= 2^21 columns when a device is present and has room.  `done` = false -> caller runs the host path.
+int preprocess_on_device(Graph &G, const int64_t *src, const int64_t *dst, int64_t E, int k, bool &done) {
+    done = false;
+    const char *env = std::getenv("UGS_DEVICE_PREPROC");
+    if (env && env[0] == '0') return UGS_OK;
+    const bool forced = env && env[0] == '1';
+    if (G.n < 1 || E < 1 || E >= ((int64_t)1 << 30)) return UGS_OK;
+    if (!forced && E < ((int64_t)1 << 21)) return UGS_OK;
+    DeviceCtx dc;
+    {
+        const std::string keep = t_err;
+        if (device_ctx(dc) != UGS_OK) { t_err = keep; return UGS_OK; }       // no device: create_preproc still works on the host
+    }
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || ugs_devpre_bytes(G.n, E) > free_b / 2) return UGS_OK;
+    UgsDevPre *d = nullptr;
+    struct Guard { UgsDevPre *&d; ~Guard() { ugs_devpre_free(d); } } guard{d};
+    G.rowptr.assign((size_t)G.n + 1, 0);
+    HIP_TRY(ugs_devpre_csr(&d, src, dst, E, G.n, dc.stream, G.rowptr.data(), &G.nnz));
+    if (G.nnz >= (int64_t)INT32_MAX) return fail(UGS_E_UNSUPPORTED, "graph too large: CSR entries must be < 2^31 - 1");
+    order_by_degree(G);
+    G.sdeg.assign((size_t)G.n, 0);
+    G.reach.assign((size_t)G.n, 0);
+    HIP_TRY(ugs_devpre_roots(d, G.order.data(), G.rank.data(), k, G.sdeg.data(), G.reach.data()));
+    G.nbr.resize((size_t)G.nnz);
+    G.col.resize((size_t)G.nnz);
+    HIP_TRY(ugs_devpre_download(d, G.nbr.data(), G.col.data()));
+    if (debug_on()) std::fprintf(stderr, "[UGS PREPROC] n=%lld columns=%lld: CSR, suffix degrees and reachability built on the device\n", (long long)G.n, (long long)E);
+    done = true;
+    return UGS_OK;
+}
 
 int assemble_plan(const std::vector<PlanPiece> &pieces, const DeviceCtx &dc, ugs_plan *plan) {
     const int64_t G = (int64_t)pieces.size();
