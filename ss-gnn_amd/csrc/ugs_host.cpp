@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <list>
 #include <map>
 #include <memory>
@@ -42,6 +43,9 @@ hipError_t ugs_devpre_csr(UgsDevPre **out, const int64_t *h_src, const int64_t *
 hipError_t ugs_devpre_roots(UgsDevPre *d, const int32_t *h_order, const int32_t *h_rank, int k, int32_t *h_sdeg, uint8_t *h_reach);
 hipError_t ugs_devpre_download(UgsDevPre *d, int32_t *h_nbr, int32_t *h_col);
 void ugs_devpre_free(UgsDevPre *d);
+void ugs_devpre_trim(UgsDevPre *d);
+size_t ugs_devpre_resident_bytes(const UgsDevPre *d);
+hipError_t ugs_devpre_assemble(UgsDevPre *d, const int64_t *h_colmap, int64_t cols, int2 *adj, int2 *adjf, hipStream_t s);
 
 namespace {
 
@@ -49,6 +53,11 @@ thread_local std::string t_err;
 int fail(int code, const std::string &msg) { t_err = msg; return code; }
 int fail_hip(hipError_t e, const char *what) { return fail(UGS_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail_hip(e_, #expr); } while (0)
+
+struct Lap {   // UGS_DEBUG=1: wall-clock of the host stages of a large preprocessing / plan build
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    double operator()() { auto n = std::chrono::steady_clock::now(); double d = std::chrono::duration<double>(n - t).count(); t = n; return d; }
+};
 
 bool debug_on() { static const bool on = [] { const char *e = std::getenv("UGS_DEBUG"); return e && std::string(e) == "1"; }(); return on; }
 
@@ -74,7 +83,11 @@ struct Graph {
     double sb_deg = 0.0;              // size-biased mean CSR degree (sum d^2 / sum d)
     std::mutex plan_mu;
     ugs_plan *plan = nullptr;         // device-resident copy for the handle API, built on first sample()
-    ~Graph() { if (plan) plan_unref(plan); }
+    std::mutex pre_mu;
+    UgsDevPre *devpre = nullptr;      // device CSR left by preprocess_on_device for the FIRST plan assembled from this graph
+    int devpre_dev = -1;
+    UgsDevPre *take_devpre(int dev) { std::lock_guard<std::mutex> lk(pre_mu); if (!devpre || devpre_dev != dev) return nullptr; UgsDevPre *d = devpre; devpre = nullptr; return d; }
+    ~Graph() { if (plan) plan_unref(plan); if (devpre) ugs_devpre_free(devpre); }
 };
 
 // CSR of the symmetrised multigraph, entries in column order (both endpoints of column j, u's row first).
@@ -233,7 +246,9 @@ int make_graph(const int64_t *src, const int64_t *dst, int64_t E, int64_t n, int
         order_by_degree(*G);
         root_stats_host(*G, k);
     }
+    Lap lap;
     weigh_roots(*G, k);
+    if (debug_on() && E >= ((int64_t)1 << 21)) std::fprintf(stderr, "[UGS PREPROC] weights, Z, alias table (host) %.3fs\n", lap());
     out = std::move(G);
     return UGS_OK;
 }
@@ -423,6 +438,7 @@ struct PlanPiece {                 // one graph of a plan
     std::shared_ptr<Graph> g;      // null for degenerate graphs
     int64_t lo = 0;
     const int64_t *colmap = nullptr;   // batch column of each of the graph's columns (null: identity)
+    int64_t ncols = 0;                 // entries of colmap
 };
 
 size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -446,17 +462,25 @@ int preprocess_on_device(Graph &G, const int64_t *src, const int64_t *dst, int64
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || ugs_devpre_bytes(G.n, E) > free_b / 2) return UGS_OK;
     UgsDevPre *d = nullptr;
     struct Guard { UgsDevPre *&d; ~Guard() { ugs_devpre_free(d); } } guard{d};
+    Lap lap;
     G.rowptr.assign((size_t)G.n + 1, 0);
     HIP_TRY(ugs_devpre_csr(&d, src, dst, E, G.n, dc.stream, G.rowptr.data(), &G.nnz));
     if (G.nnz >= (int64_t)INT32_MAX) return fail(UGS_E_UNSUPPORTED, "graph too large: CSR entries must be < 2^31 - 1");
+    const double t_csr = lap();
     order_by_degree(G);
+    const double t_order = lap();
     G.sdeg.assign((size_t)G.n, 0);
     G.reach.assign((size_t)G.n, 0);
     HIP_TRY(ugs_devpre_roots(d, G.order.data(), G.rank.data(), k, G.sdeg.data(), G.reach.data()));
+    const double t_roots = lap();
     G.nbr.resize((size_t)G.nnz);
     G.col.resize((size_t)G.nnz);
     HIP_TRY(ugs_devpre_download(d, G.nbr.data(), G.col.data()));
-    if (debug_on()) std::fprintf(stderr, "[UGS PREPROC] n=%lld columns=%lld: CSR, suffix degrees and reachability built on the device\n", (long long)G.n, (long long)E);
+    if (debug_on())
+        std::fprintf(stderr, "[UGS PREPROC] n=%lld columns=%lld on the device: upload+CSR %.3fs, degree order (host) %.3fs, suffix degrees+reachability %.3fs, "
+                     "CSR download %.3fs\n", (long long)G.n, (long long)E, t_csr, t_order, t_roots, lap());
+    ugs_devpre_trim(d);
+    { std::lock_guard<std::mutex> lk(G.pre_mu); G.devpre = d; G.devpre_dev = dc.id; d = nullptr; }
     done = true;
     return UGS_OK;
 }
@@ -473,15 +497,43 @@ int assemble_plan(const std::vector<PlanPiece> &pieces, const DeviceCtx &dc, ugs
     size_t off_root = align_up(off_col + (size_t)std::max<int64_t>(nnz, 1) * sizeof(int2));
     size_t off_via = align_up(off_root + (size_t)std::max<int64_t>(nv, 1) * sizeof(UgsRootRec));
     size_t total = align_up(off_via + (size_t)std::max<int64_t>(nviable, 1) * sizeof(int2));
-    std::vector<char> host(total, 0);
+    // Graphs preprocessed on this device still hold their CSR in HBM (Graph::devpre): their adjacency arrays are written by
+    // a kernel and never cross the bus.  Without such a piece (every batch of small graphs) the plan is ONE host blob, one copy.
+    std::vector<UgsDevPre *> dpre((size_t)G, nullptr);
+    bool split = false;
+    for (int64_t gi = 0; gi < G; ++gi)
+        if (pieces[(size_t)gi].g && (dpre[(size_t)gi] = pieces[(size_t)gi].g->take_devpre(dc.id))) split = true;
+    struct Owned { std::vector<UgsDevPre *> &v; ~Owned() { for (auto *d : v) ugs_devpre_free(d); } } owned{dpre};
+    std::vector<char> host(split ? off_adj : total, 0);           // split: head = descriptors + row pointer
+    std::vector<char> tail(split ? total - off_root : 0, 0);      // split: tail = root records + viable lists
     auto *desc = reinterpret_cast<UgsGraphDesc *>(host.data() + off_desc);
     auto *rowp = reinterpret_cast<int64_t *>(host.data() + off_row);
-    auto *adj = reinterpret_cast<int2 *>(host.data() + off_adj);
-    auto *adjf = reinterpret_cast<int2 *>(host.data() + off_col);
-    auto *roots = reinterpret_cast<UgsRootRec *>(host.data() + off_root);
-    auto *via = reinterpret_cast<int2 *>(host.data() + off_via);
+    auto *adj = split ? nullptr : reinterpret_cast<int2 *>(host.data() + off_adj);
+    auto *adjf = split ? nullptr : reinterpret_cast<int2 *>(host.data() + off_col);
+    char *tail_base = split ? tail.data() - off_root : host.data();
+    auto *roots = reinterpret_cast<UgsRootRec *>(tail_base + off_root);
+    auto *via = reinterpret_cast<int2 *>(tail_base + off_via);
+    void *dptr = nullptr;
+    if (total <= ((size_t)64 << 20)) {      // batches of small graphs come and go with every shuffled mini-batch: pooled
+        if (int rc = pool_get(total, dc.id, plan->blob_buf)) return rc;
+        dptr = plan->blob_buf.p;
+    } else {
+        HIP_TRY(hipMalloc(&dptr, total));
+    }
+    auto give_back = [&] { if (plan->blob_buf.p) { pool_put(plan->blob_buf); plan->blob_buf = PoolBuf(); } else (void)hipFree(dptr); };
+    char *base = static_cast<char *>(dptr);
+    auto fill_adj = [](const PlanPiece &pc, int2 *a, int2 *af) {
+        const Graph &g = *pc.g;
+        for (int64_t p = 0; p < g.nnz; ++p) {
+            const int32_t w = g.nbr[(size_t)p];
+            a[p] = make_int2(w, g.rank[(size_t)w]);
+            const int32_t c = g.col[(size_t)p];
+            af[p] = make_int2(w, pc.colmap ? (int32_t)pc.colmap[c] : c);
+        }
+    };
     int64_t rb = 0, vb = 0, ab = 0, vib = 0;
     plan->g_n.resize((size_t)G); plan->g_maxdeg.resize((size_t)G); plan->g_sbdeg.resize((size_t)G); plan->g_level.resize((size_t)G);
+    std::vector<int2> tmp_a, tmp_f;
     for (int64_t gi = 0; gi < G; ++gi) {
         const PlanPiece &pc = pieces[(size_t)gi];
         UgsGraphDesc &d = desc[gi];
@@ -491,11 +543,21 @@ int assemble_plan(const std::vector<PlanPiece> &pieces, const DeviceCtx &dc, ugs
         d.n = (int32_t)g.n; d.level = g.level; d.n_viable = (int32_t)g.viable.size();
         plan->g_n[(size_t)gi] = g.n; plan->g_maxdeg[(size_t)gi] = g.max_deg; plan->g_sbdeg[(size_t)gi] = g.sb_deg; plan->g_level[(size_t)gi] = g.level;
         for (int64_t r = 0; r <= g.n; ++r) rowp[rb + r] = ab + g.rowptr[(size_t)r];
-        for (int64_t p = 0; p < g.nnz; ++p) {
-            const int32_t w = g.nbr[(size_t)p];
-            adj[ab + p] = make_int2(w, g.rank[(size_t)w]);
-            const int32_t c = g.col[(size_t)p];
-            adjf[ab + p] = make_int2(w, pc.colmap ? (int32_t)pc.colmap[c] : c);
+        if (!split) fill_adj(pc, adj + ab, adjf + ab);
+        else {
+            int2 *d_adj = reinterpret_cast<int2 *>(base + off_adj) + ab, *d_adjf = reinterpret_cast<int2 *>(base + off_col) + ab;
+            hipError_t e = hipSuccess;
+            if (UgsDevPre *dp = dpre[(size_t)gi]) {
+                const int64_t *cm = pc.colmap;
+                if (cm) { bool ident = true; for (int64_t c = 0; c < pc.ncols && ident; ++c) ident = cm[c] == c; if (ident) cm = nullptr; }
+                e = ugs_devpre_assemble(dp, cm, pc.ncols, d_adj, d_adjf, dc.stream);
+            } else if (g.nnz > 0) {
+                tmp_a.resize((size_t)g.nnz); tmp_f.resize((size_t)g.nnz);
+                fill_adj(pc, tmp_a.data(), tmp_f.data());
+                e = hipMemcpy(d_adj, tmp_a.data(), (size_t)g.nnz * sizeof(int2), hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(d_adjf, tmp_f.data(), (size_t)g.nnz * sizeof(int2), hipMemcpyHostToDevice);
+            }
+            if (e != hipSuccess) { give_back(); return fail_hip(e, "plan adjacency"); }
         }
         if (g.level == 0)
             for (int64_t vi = 0; vi < g.n; ++vi) {
@@ -507,19 +569,12 @@ int assemble_plan(const std::vector<PlanPiece> &pieces, const DeviceCtx &dc, ugs
             for (size_t t = 0; t < g.viable.size(); ++t) via[vib + (int64_t)t] = make_int2(g.viable[t], g.order[(size_t)g.viable[t]]);
         rb += g.n + 1; vb += g.n; ab += g.nnz; if (g.level > 0) vib += (int64_t)g.viable.size();
     }
-    void *dptr = nullptr;
-    if (total <= ((size_t)64 << 20)) {      // batches of small graphs come and go with every shuffled mini-batch: pooled
-        if (int rc = pool_get(total, dc.id, plan->blob_buf)) return rc;
-        dptr = plan->blob_buf.p;
-    } else {
-        HIP_TRY(hipMalloc(&dptr, total));
-    }
-    hipError_t e = hipMemcpy(dptr, host.data(), total, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { if (plan->blob_buf.p) pool_put(plan->blob_buf); else (void)hipFree(dptr); return fail_hip(e, "hipMemcpy(plan)"); }
+    hipError_t e = hipMemcpy(dptr, host.data(), host.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess && split) e = hipMemcpy(base + off_root, tail.data(), tail.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { give_back(); return fail_hip(e, "hipMemcpy(plan)"); }
     plan->device = dc.id; plan->cus = dc.cus;
     plan->G = G; plan->nverts = nv; plan->nnz = nnz;
     plan->blob = dptr; plan->blob_bytes = total;
-    char *base = static_cast<char *>(dptr);
     plan->dev.graphs = reinterpret_cast<const UgsGraphDesc *>(base + off_desc);
     plan->dev.rowptr = reinterpret_cast<const int64_t *>(base + off_row);
     plan->dev.adj = reinterpret_cast<const int2 *>(base + off_adj);
@@ -783,7 +838,9 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
     const int64_t G = num_graphs, E = num_cols;
     const int64_t *src = edge_index, *dst = edge_index + row_stride;
     std::vector<int64_t> cstart, cols_of;                      // per-graph column lists, concatenated
+    Lap lap;
     assign_columns(src, dst, E, ptr, G, cstart, cols_of);
+    const double t_assign = lap();
     // --- per graph: renumber, hash, LRU lookup / preprocessing ------------------------------------------------------
     std::vector<PlanPiece> pieces((size_t)G);
     std::vector<int64_t> ru, rv, evicted;
@@ -820,6 +877,7 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
         } else ++hits;
         pc.g = gr;
         pc.colmap = cols_of.data() + c0;
+        pc.ncols = cn;
         mix((uint64_t)handle); mix((uint64_t)cn);
         for (int64_t t = 0; t < cn; ++t) mix((uint64_t)cols_of[(size_t)(c0 + t)]);
     }
@@ -829,9 +887,12 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
         std::fprintf(stderr, "[UGS CACHE] hits=%lld misses=%lld cache_size=%zu\n", (long long)hits, (long long)misses, lru().items.size());
     }
     if (ugs_plan *cached = plan_cache_get(pkey, dc.id)) { *plan_out = cached; return UGS_OK; }
+    const double t_graphs = lap();
     auto *p = new ugs_plan();
     p->cache_key = pkey;
     if (int rc = assemble_plan(pieces, dc, p)) { delete p; return rc; }
+    if (debug_on() && E >= ((int64_t)1 << 21))
+        std::fprintf(stderr, "[UGS PLAN] columns -> graphs %.3fs, renumber + hash + preprocessing %.3fs, assemble + upload %.3fs\n", t_assign, t_graphs, lap());
     plan_cache_put(p);
     *plan_out = p;
     return UGS_OK;

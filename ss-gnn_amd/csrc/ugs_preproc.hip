@@ -75,6 +75,16 @@ __global__ void __launch_bounds__(256) pre_roots(const uint32_t *__restrict__ ro
     reach[vi] = cnt >= k ? 1 : 0;
 }
 
+// plan adjacency straight from the device CSR: adj = (neighbour, order position of neighbour), adjf = (neighbour, batch column)
+__global__ void __launch_bounds__(256) pre_assemble(const int32_t *__restrict__ nbr, const int32_t *__restrict__ col, const int32_t *__restrict__ rank,
+                                                    const int64_t *__restrict__ colmap, int64_t nnz, int2 *__restrict__ adj, int2 *__restrict__ adjf) {
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= nnz) return;
+    const int32_t w = nbr[a], c = col[a];
+    adj[a] = make_int2(w, rank[w]);
+    adjf[a] = make_int2(w, colmap ? (int32_t)colmap[c] : c);
+}
+
 inline unsigned blocks_for(int64_t items) { return (unsigned)((items + 255) / 256); }
 
 }  // namespace
@@ -178,4 +188,30 @@ hipError_t ugs_devpre_download(UgsDevPre *d, int32_t *h_nbr, int32_t *h_col) {
     PRE_TRY(hipMemcpyAsync(h_nbr, d->nbr, (size_t)d->nnz * 4, hipMemcpyDeviceToHost, d->stream));
     PRE_TRY(hipMemcpyAsync(h_col, d->col, (size_t)d->nnz * 4, hipMemcpyDeviceToHost, d->stream));
     return hipStreamSynchronize(d->stream);
+}
+
+// After stage 3 only (nbr, col, rank) are worth keeping: the first plan assembled from this graph reads them on the device.
+void ugs_devpre_trim(UgsDevPre *d) {
+    void **ps[] = {(void **)&d->src, (void **)&d->dst, (void **)&d->keys, (void **)&d->keys2, (void **)&d->vals, (void **)&d->vals2, (void **)&d->deg,
+                   (void **)&d->rowptr, (void **)&d->order, (void **)&d->sdeg, (void **)&d->reach, &d->tmp};
+    for (void **p : ps) if (*p) { (void)hipFree(*p); *p = nullptr; }
+}
+
+size_t ugs_devpre_resident_bytes(const UgsDevPre *d) { return (size_t)d->nnz * 8 + (size_t)d->n * 4; }
+
+// adj / adjf of a plan (device pointers to this graph's nnz entries).  `h_colmap` (host, `cols` int64 entries, or null for the
+// identity) maps the graph's own column numbers to batch columns.
+hipError_t ugs_devpre_assemble(UgsDevPre *d, const int64_t *h_colmap, int64_t cols, int2 *adj, int2 *adjf, hipStream_t s) {
+    if (d->nnz == 0) return hipSuccess;
+    int64_t *cm = nullptr;
+    if (h_colmap && cols > 0) {
+        PRE_TRY(hipMalloc(&cm, (size_t)cols * 8));
+        hipError_t e = hipMemcpyAsync(cm, h_colmap, (size_t)cols * 8, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) { (void)hipFree(cm); return e; }
+    }
+    pre_assemble<<<blocks_for(d->nnz), 256, 0, s>>>(d->nbr, d->col, d->rank, cm, d->nnz, adj, adjf);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (cm) (void)hipFree(cm);
+    return e;
 }

@@ -108,3 +108,38 @@ def test_default_threshold_large_graph_equals_host_path():
     os.environ.pop("UGS_DEVICE_PREPROC", None)
     for key in d0:
         assert np.array_equal(d[key], d0[key]), key
+
+
+def test_plan_assembled_from_device_and_host_pieces(forced_device):
+    """One batch whose graphs are partly LRU hits preprocessed on the host and partly new graphs whose CSR is still in HBM:
+    the plan's adjacency is written by a kernel for the latter, copied for the former; columns shuffled (non-identity map)."""
+    import ugs_sampler
+    rng = random.Random(4)
+    sizes = [30, 45, 60, 25]
+    graphs = []
+    for n in sizes:
+        e = [(u, v) for u in range(n) for v in range(u + 1, n) if rng.random() < 0.2]
+        graphs.append((n, e + [(v, u) for u, v in e]))
+
+    def batch(idx, shuffle):
+        cols, ptr = [], [0]
+        for i in idx:
+            n, e = graphs[i]
+            cols += [(u + ptr[-1], v + ptr[-1]) for u, v in e]
+            ptr.append(ptr[-1] + n)
+        if shuffle:
+            rng.shuffle(cols)
+        return np.array(cols, dtype=np.int64).T.reshape(2, -1).copy(), np.array(ptr, dtype=np.int64)
+
+    ugs_sampler.clear_cache()
+    os.environ["UGS_DEVICE_PREPROC"] = "0"
+    ei, ptr = batch([0, 1], False)
+    ugs_sampler.sample_batch(torch.from_numpy(ei), torch.from_numpy(ptr), 8, 4, "sample", 1)        # graphs 0, 1 -> LRU (host)
+    os.environ["UGS_DEVICE_PREPROC"] = "1"
+    for idx, shuffle, mode in (([2, 0, 3, 1], True, "sample"), ([1, 2, 3], False, "global"), ([3, 3, 0], True, "graph")):
+        ei, ptr = batch(idx, shuffle)
+        got = ugs_sampler.sample_batch(torch.from_numpy(ei), torch.from_numpy(ptr), 50, 4, mode, 9)
+        want = oracle.sample_batch(ei, ptr, 50, 4, mode, 9)
+        for g, w in zip(got, want):
+            assert np.array_equal(g.numpy(), np.asarray(w)), (idx, mode)
+    ugs_sampler.clear_cache()
