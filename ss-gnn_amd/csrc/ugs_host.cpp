@@ -241,10 +241,16 @@ int make_graph(const int64_t *src, const int64_t *dst, int64_t E, int64_t n, int
     bool on_device = false;
     if (int rc = preprocess_on_device(*G, src, dst, E, k, on_device)) return rc;
     if (!on_device) {
+        Lap lap;
         build_adjacency(*G, src, dst, E);
         if (G->nnz >= (int64_t)INT32_MAX) return fail(UGS_E_UNSUPPORTED, "graph too large: CSR entries must be < 2^31 - 1");
+        const double t_csr = lap();
         order_by_degree(*G);
+        const double t_order = lap();
         root_stats_host(*G, k);
+        if (debug_on() && E >= ((int64_t)1 << 21))
+            std::fprintf(stderr, "[UGS PREPROC] n=%lld columns=%lld on the host: CSR %.3fs, degree order %.3fs, suffix degrees+reachability %.3fs\n",
+                         (long long)n, (long long)E, t_csr, t_order, lap());
     }
     Lap lap;
     weigh_roots(*G, k);
