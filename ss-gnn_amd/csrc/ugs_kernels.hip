@@ -375,6 +375,51 @@ __device__ __forceinline__ void stage_mat(const Work<LdsSpace> &ws, const Grp<GS
     LdsSpace::sync();
 }
 
+// Stages of at most 64 elements with one walk per wave: ONE element per lane and no bucket table at all.  A radix pass of
+// ballots over the bits of the bucket number leaves every lane with the 64-bit mask of the lanes that share its bucket;
+// popcounts of that mask give the bucket's size, its first position (the leader) and the number of members above the lane,
+// one DPP scan of the sizes over the leaders gives every bucket's start and one ds_bpermute fetches the leader's start.
+// rank = start + members above -- the same definition as stage_mat, with no LDS traffic except the element itself.
+__device__ __forceinline__ uint32_t rank_in_registers(const Grp<64> &g, bool valid, uint32_t bk, uint32_t nbits) {
+    uint64_t mates = __ballot(valid);
+    for (uint32_t bit = 0; bit < nbits; ++bit) {
+        const bool set = (bk >> bit) & 1u;
+        const uint64_t b = __ballot(set);
+        mates &= set ? b : ~b;
+    }
+    const uint32_t size = (uint32_t)__popcll(mates);
+    const uint32_t first = valid ? (uint32_t)(__ffsll((long long)mates) - 1) : (uint32_t)g.lane;
+    const uint32_t above = (uint32_t)__popcll(mates & (~1ull << g.lane));
+    const uint32_t lead = (valid && first == (uint32_t)g.lane) ? size : 0u;
+    const uint32_t incl = g.prefix_incl(lead);
+    const uint32_t run = g.last(incl) - incl;                              // ranks taken by buckets led from higher lanes
+    const uint32_t start = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(first << 2), (int)run);
+    return start + above;
+}
+
+__device__ __forceinline__ void stage_mat_reg(const Work<LdsSpace> &ws, const Grp<64> &g, const uint32_t *OLD, uint32_t *NEW,
+                                              uint32_t n_old, uint32_t B, uint32_t M, uint32_t S) {
+    const uint32_t t = (uint32_t)g.lane;
+    const bool valid = t < B;
+    uint32_t key = 0u;
+    if (valid) key = (t < n_old) ? OLD[t] : ws.D[t];
+    const uint32_t rank = rank_in_registers(g, valid, mod_magic(key, B, M, S), S + 1u);
+    if (valid) NEW[rank] = key;
+    LdsSpace::sync();
+}
+
+__device__ __forceinline__ uint32_t stage_final_reg(const Work<LdsSpace> &ws, const Grp<64> &g, const uint32_t *OLD, uint32_t n_old,
+                                                    uint32_t L, uint32_t B, uint32_t M, uint32_t S, uint32_t rsel) {
+    const uint32_t t = (uint32_t)g.lane;
+    const bool valid = t < L;
+    uint32_t key = 0u;
+    if (valid) key = (t < n_old) ? OLD[t] : ws.D[t];
+    const uint32_t rank = rank_in_registers(g, valid, mod_magic(key, B, M, S), S + 1u);
+    const uint64_t hm = __ballot(valid && rank == rsel);
+    const int src = hm ? (__ffsll((long long)hm) - 1) : 0;
+    return g.bcast(key, src);
+}
+
 // The LAST stage only has to name the element at iteration position `rsel`, so nothing is ranked or materialised:
 // one atomicMin (first position of every bucket) and one atomicAdd (its size) on the same word, a scan of the sizes
 // over the bucket leaders to find the bucket that holds position rsel, and ballots among that bucket's few members.
@@ -459,6 +504,7 @@ __device__ __forceinline__ uint32_t select_lds(const Work<LdsSpace> &ws, const G
         uint32_t *NEW = ws.ORD + d_chain.O[stage];
         const uint32_t n_old = stage ? d_chain.B[stage - 1] : 0u;
         const uint32_t per = (B + GS - 1) / GS;                             // these stages are full: L == B
+        if constexpr (GS == 64) { if (per <= 1) { stage_mat_reg(ws, g, OLD, NEW, n_old, B, M, S); nvalid = stage + 1; continue; } }
         if (per <= 1) stage_mat<GS, 1>(ws, g, OLD, NEW, n_old, B, M, S);
         else if (per <= 3) stage_mat<GS, 3>(ws, g, OLD, NEW, n_old, B, M, S);
         else if (per <= 5) stage_mat<GS, 5>(ws, g, OLD, NEW, n_old, B, M, S);
@@ -476,6 +522,7 @@ __device__ __forceinline__ uint32_t select_lds(const Work<LdsSpace> &ws, const G
         const uint32_t *OLD = fs ? ws.ORD + d_chain.O[fs - 1] : ws.D;
         const uint32_t n_old = fs ? d_chain.B[fs - 1] : 0u;
         const uint32_t per = (c + GS - 1) / GS;
+        if constexpr (GS == 64) { if (per <= 1) return stage_final_reg(ws, g, OLD, n_old, c, B, M, S, rsel); }
         if (per <= 1) return stage_final<GS, 1>(ws, g, OLD, n_old, c, B, M, S, rsel);
         else if (per <= 3) return stage_final<GS, 3>(ws, g, OLD, n_old, c, B, M, S, rsel);
         else if (per <= 5) return stage_final<GS, 5>(ws, g, OLD, n_old, c, B, M, S, rsel);
