@@ -420,6 +420,71 @@ __device__ __forceinline__ uint32_t stage_final_reg(const Work<LdsSpace> &ws, co
     return g.bcast(key, src);
 }
 
+// The same for 65..128 elements: lane l holds positions l (slot 0) and 64 + l (slot 1); four mate masks (own slot x other
+// slot).  Positions are slot-major, so a bucket's leader is in slot 0 whenever it has a member there, and the buckets led
+// from slot 1 (the later positions) are laid out first.
+struct Rank2 { uint32_t r0, r1; };
+__device__ __forceinline__ Rank2 rank2_in_registers(const Grp<64> &g, bool valid1, uint32_t bk0, uint32_t bk1, uint32_t nbits) {
+    const uint64_t v1 = __ballot(valid1);
+    uint64_t m00 = ~0ull, m01 = v1, m10 = ~0ull, m11 = v1;              // slot 0 is full
+    for (uint32_t bit = 0; bit < nbits; ++bit) {
+        const bool s0 = (bk0 >> bit) & 1u, s1 = (bk1 >> bit) & 1u;
+        const uint64_t b0 = __ballot(s0), b1 = __ballot(s1);
+        m00 &= s0 ? b0 : ~b0;  m01 &= s0 ? b1 : ~b1;
+        m10 &= s1 ? b0 : ~b0;  m11 &= s1 ? b1 : ~b1;
+    }
+    const uint64_t gt = ~1ull << g.lane;
+    const uint32_t lane = (uint32_t)g.lane;
+    // element in slot 0: its bucket's leader is the lowest slot-0 mate (itself included)
+    const uint32_t first0 = (uint32_t)(__ffsll((long long)m00) - 1);
+    const uint32_t size0 = (uint32_t)(__popcll(m00) + __popcll(m01));
+    const uint32_t above0 = (uint32_t)(__popcll(m00 & gt) + __popcll(m01));
+    const uint32_t lead0 = first0 == lane ? size0 : 0u;
+    // element in slot 1: led from slot 0 if it has a mate there, else by the lowest slot-1 mate
+    const bool from0 = m10 != 0ull;
+    const uint32_t first1 = valid1 ? (uint32_t)(__ffsll((long long)(from0 ? m10 : m11)) - 1) : lane;
+    const uint32_t above1 = (uint32_t)__popcll(m11 & gt);
+    const uint32_t lead1 = (valid1 && !from0 && first1 == lane) ? (uint32_t)__popcll(m11) : 0u;
+    const uint32_t incl1 = g.prefix_incl(lead1), tot1 = g.last(incl1);
+    const uint32_t incl0 = g.prefix_incl(lead0);
+    const uint32_t run1 = tot1 - incl1;                                   // buckets led from slot 1, higher lanes first
+    const uint32_t run0 = tot1 + (g.last(incl0) - incl0);                 // then those led from slot 0
+    const uint32_t st0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(first0 << 2), (int)run0);
+    const uint32_t st1a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(first1 << 2), (int)run0);
+    const uint32_t st1b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(first1 << 2), (int)run1);
+    Rank2 r;
+    r.r0 = st0 + above0;
+    r.r1 = (from0 ? st1a : st1b) + above1;
+    return r;
+}
+
+__device__ __forceinline__ void stage_mat_reg2(const Work<LdsSpace> &ws, const Grp<64> &g, const uint32_t *OLD, uint32_t *NEW,
+                                               uint32_t n_old, uint32_t B, uint32_t M, uint32_t S) {
+    const uint32_t t0 = (uint32_t)g.lane, t1 = t0 + 64u;
+    const bool valid1 = t1 < B;
+    const uint32_t key0 = (t0 < n_old) ? OLD[t0] : ws.D[t0];
+    uint32_t key1 = 0u;
+    if (valid1) key1 = (t1 < n_old) ? OLD[t1] : ws.D[t1];
+    const Rank2 r = rank2_in_registers(g, valid1, mod_magic(key0, B, M, S), mod_magic(key1, B, M, S), S + 1u);
+    NEW[r.r0] = key0;
+    if (valid1) NEW[r.r1] = key1;
+    LdsSpace::sync();
+}
+
+__device__ __forceinline__ uint32_t stage_final_reg2(const Work<LdsSpace> &ws, const Grp<64> &g, const uint32_t *OLD, uint32_t n_old,
+                                                     uint32_t L, uint32_t B, uint32_t M, uint32_t S, uint32_t rsel) {
+    const uint32_t t0 = (uint32_t)g.lane, t1 = t0 + 64u;
+    const bool valid1 = t1 < L;
+    const uint32_t key0 = (t0 < n_old) ? OLD[t0] : ws.D[t0];
+    uint32_t key1 = 0u;
+    if (valid1) key1 = (t1 < n_old) ? OLD[t1] : ws.D[t1];
+    const Rank2 r = rank2_in_registers(g, valid1, mod_magic(key0, B, M, S), mod_magic(key1, B, M, S), S + 1u);
+    const bool h0 = r.r0 == rsel, h1 = valid1 && r.r1 == rsel;
+    const uint64_t hm = __ballot(h0 || h1);
+    const int src = hm ? (__ffsll((long long)hm) - 1) : 0;
+    return g.bcast(h0 ? key0 : key1, src);
+}
+
 // The LAST stage only has to name the element at iteration position `rsel`, so nothing is ranked or materialised:
 // one atomicMin (first position of every bucket) and one atomicAdd (its size) on the same word, a scan of the sizes
 // over the bucket leaders to find the bucket that holds position rsel, and ballots among that bucket's few members.
@@ -504,7 +569,10 @@ __device__ __forceinline__ uint32_t select_lds(const Work<LdsSpace> &ws, const G
         uint32_t *NEW = ws.ORD + d_chain.O[stage];
         const uint32_t n_old = stage ? d_chain.B[stage - 1] : 0u;
         const uint32_t per = (B + GS - 1) / GS;                             // these stages are full: L == B
-        if constexpr (GS == 64) { if (per <= 1) { stage_mat_reg(ws, g, OLD, NEW, n_old, B, M, S); nvalid = stage + 1; continue; } }
+        if constexpr (GS == 64) {
+            if (per <= 1) { stage_mat_reg(ws, g, OLD, NEW, n_old, B, M, S); nvalid = stage + 1; continue; }
+            if (per <= 2) { stage_mat_reg2(ws, g, OLD, NEW, n_old, B, M, S); nvalid = stage + 1; continue; }
+        }
         if (per <= 1) stage_mat<GS, 1>(ws, g, OLD, NEW, n_old, B, M, S);
         else if (per <= 3) stage_mat<GS, 3>(ws, g, OLD, NEW, n_old, B, M, S);
         else if (per <= 5) stage_mat<GS, 5>(ws, g, OLD, NEW, n_old, B, M, S);
@@ -522,7 +590,10 @@ __device__ __forceinline__ uint32_t select_lds(const Work<LdsSpace> &ws, const G
         const uint32_t *OLD = fs ? ws.ORD + d_chain.O[fs - 1] : ws.D;
         const uint32_t n_old = fs ? d_chain.B[fs - 1] : 0u;
         const uint32_t per = (c + GS - 1) / GS;
-        if constexpr (GS == 64) { if (per <= 1) return stage_final_reg(ws, g, OLD, n_old, c, B, M, S, rsel); }
+        if constexpr (GS == 64) {
+            if (per <= 1) return stage_final_reg(ws, g, OLD, n_old, c, B, M, S, rsel);
+            if (per <= 2) return stage_final_reg2(ws, g, OLD, n_old, c, B, M, S, rsel);
+        }
         if (per <= 1) return stage_final<GS, 1>(ws, g, OLD, n_old, c, B, M, S, rsel);
         else if (per <= 3) return stage_final<GS, 3>(ws, g, OLD, n_old, c, B, M, S, rsel);
         else if (per <= 5) return stage_final<GS, 5>(ws, g, OLD, n_old, c, B, M, S, rsel);
