@@ -380,13 +380,21 @@ __device__ __forceinline__ void stage_mat(const Work<LdsSpace> &ws, const Grp<GS
 // popcounts of that mask give the bucket's size, its first position (the leader) and the number of members above the lane,
 // one DPP scan of the sizes over the leaders gives every bucket's start and one ds_bpermute fetches the leader's start.
 // rank = start + members above -- the same definition as stage_mat, with no LDS traffic except the element itself.
+__device__ __forceinline__ uint32_t spread_bit(uint32_t v, uint32_t bit) {     // 0 or 0xFFFFFFFF (v_bfe_i32)
+    return (uint32_t)((int32_t)(v << (31u - bit)) >> 31);
+}
+
 __device__ __forceinline__ uint32_t rank_in_registers(const Grp<64> &g, bool valid, uint32_t bk, uint32_t nbits) {
-    uint64_t mates = __ballot(valid);
+    // mates &= (own bit set ? b : ~b), written per 32-bit half as m & ~(b ^ x) with x = 0 / ~0: one v_bitop3_b32 each
+    const uint64_t v = __ballot(valid);
+    uint32_t mlo = (uint32_t)v, mhi = (uint32_t)(v >> 32);
     for (uint32_t bit = 0; bit < nbits; ++bit) {
-        const bool set = (bk >> bit) & 1u;
-        const uint64_t b = __ballot(set);
-        mates &= set ? b : ~b;
+        const uint32_t x = spread_bit(bk, bit);
+        const uint64_t b = __ballot(x != 0u);
+        mlo &= ~((uint32_t)b ^ x);
+        mhi &= ~((uint32_t)(b >> 32) ^ x);
     }
+    const uint64_t mates = ((uint64_t)mhi << 32) | mlo;
     const uint32_t size = (uint32_t)__popcll(mates);
     const uint32_t first = valid ? (uint32_t)(__ffsll((long long)mates) - 1) : (uint32_t)g.lane;
     const uint32_t above = (uint32_t)__popcll(mates & (~1ull << g.lane));
@@ -426,13 +434,17 @@ __device__ __forceinline__ uint32_t stage_final_reg(const Work<LdsSpace> &ws, co
 struct Rank2 { uint32_t r0, r1; };
 __device__ __forceinline__ Rank2 rank2_in_registers(const Grp<64> &g, bool valid1, uint32_t bk0, uint32_t bk1, uint32_t nbits) {
     const uint64_t v1 = __ballot(valid1);
-    uint64_t m00 = ~0ull, m01 = v1, m10 = ~0ull, m11 = v1;              // slot 0 is full
+    const uint32_t v1l = (uint32_t)v1, v1h = (uint32_t)(v1 >> 32);
+    uint32_t a00 = ~0u, b00 = ~0u, a01 = v1l, b01 = v1h, a10 = ~0u, b10 = ~0u, a11 = v1l, b11 = v1h;   // (low, high) halves; slot 0 is full
     for (uint32_t bit = 0; bit < nbits; ++bit) {
-        const bool s0 = (bk0 >> bit) & 1u, s1 = (bk1 >> bit) & 1u;
-        const uint64_t b0 = __ballot(s0), b1 = __ballot(s1);
-        m00 &= s0 ? b0 : ~b0;  m01 &= s0 ? b1 : ~b1;
-        m10 &= s1 ? b0 : ~b0;  m11 &= s1 ? b1 : ~b1;
+        const uint32_t x0 = spread_bit(bk0, bit), x1 = spread_bit(bk1, bit);
+        const uint64_t q0 = __ballot(x0 != 0u), q1 = __ballot(x1 != 0u);
+        const uint32_t q0l = (uint32_t)q0, q0h = (uint32_t)(q0 >> 32), q1l = (uint32_t)q1, q1h = (uint32_t)(q1 >> 32);
+        a00 &= ~(q0l ^ x0); b00 &= ~(q0h ^ x0);  a01 &= ~(q1l ^ x0); b01 &= ~(q1h ^ x0);
+        a10 &= ~(q0l ^ x1); b10 &= ~(q0h ^ x1);  a11 &= ~(q1l ^ x1); b11 &= ~(q1h ^ x1);
     }
+    const uint64_t m00 = ((uint64_t)b00 << 32) | a00, m01 = ((uint64_t)b01 << 32) | a01;
+    const uint64_t m10 = ((uint64_t)b10 << 32) | a10, m11 = ((uint64_t)b11 << 32) | a11;
     const uint64_t gt = ~1ull << g.lane;
     const uint32_t lane = (uint32_t)g.lane;
     // element in slot 0: its bucket's leader is the lowest slot-0 mate (itself included)
