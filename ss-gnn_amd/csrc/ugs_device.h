@@ -74,7 +74,17 @@ struct UgsWalkArgs {
     int32_t ghs;             // hash slots (power of two) of the global tier
     int32_t gbcap;           // bucket-table entries of the global tier
     int32_t gpcap;           // words of all materialised stage orders of the global tier
+    // induced edges staged by the walk itself (one-walk-per-wave LDS tiers; NULL = off): the walk meets every induced edge
+    // when it scans the row of the later endpoint, so complete rows leave their directed edge items here in OUTPUT order
+    // and the fill kernel only expands them.  Rows that do not fit (or ran in a tier without staging) are flagged 0 and,
+    // if they have edges, listed for the row-reading fill kernel.
+    uint2 *stage;            // [row_count, UGS_STAGE_ITEMS]: x = batch column, y = source local index | target local index << 8
+    uint8_t *staged;         // [row_count] 1 = row's items are in `stage`
+    int64_t *ulist;          // rows (relative) with edges that are NOT staged
+    uint32_t *ucount;
 };
+#define UGS_STAGE_ENTRIES 32    /* undirected hits a walk can hold in LDS */
+#define UGS_STAGE_ITEMS 64      /* directed items per row in the staging buffer */
 
 struct UgsFillArgs {
     UgsPlanDev plan;
@@ -86,6 +96,10 @@ struct UgsFillArgs {
     int64_t *edge_index;       // [2, ld]
     int64_t ld;
     int64_t *edge_src;
+    const uint2 *stage;        // staging left by the walk of the same rows (NULL: every row is filled from its adjacency rows)
+    const uint8_t *staged;
+    const int64_t *ulist;      // with staging: the rows the row-reading kernel still has to do
+    const uint32_t *ucount;
 };
 
 struct UgsLaunchInfo {

@@ -426,6 +426,13 @@ struct ugs_plan {
     bool cached = false;
     // lazily grown scratch owned by the plan (serialised by `mu` per call)
     PoolBuf counts, ovf1, ovf2, ovfcnt, scantmp, gws;
+    // edges staged by the last walk (UgsWalkArgs::stage) and the call they belong to: a fill of exactly those rows into/from
+    // the same nodes buffer expands them; any other fill reads the adjacency rows again
+    PoolBuf stage, staged, ulist;
+    bool stg_valid = false;
+    const void *stg_nodes = nullptr;
+    int64_t stg_row_begin = 0, stg_row_count = 0;
+    int stg_m = 0, stg_k = 0;
     int64_t gws_groups = 0, gws_words = 0;
     int gcap = 0, ghs = 0, gbcap = 0, gpcap = 0;
     UgsLaunchInfo last_walk{nullptr, 0, 0, 0};
@@ -615,6 +622,7 @@ void destroy_plan(ugs_plan *p) {
     ev_clear(p);
     if (p->blob_buf.p) pool_put(p->blob_buf); else if (p->blob) (void)hipFree(p->blob);
     pool_put(p->counts); pool_put(p->ovf1); pool_put(p->ovf2); pool_put(p->ovfcnt); pool_put(p->scantmp);
+    pool_put(p->stage); pool_put(p->staged); pool_put(p->ulist);
     if (p->gws.p) { (void)hipFree(p->gws.p); p->gws = PoolBuf(); }
     delete p;
 }
@@ -942,7 +950,16 @@ int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
         if (int rc = ensure(plan->ovf1, (size_t)row_count * sizeof(int64_t), plan->device)) return rc;
         if (int rc = ensure(plan->ovf2, (size_t)row_count * sizeof(int64_t), plan->device)) return rc;
     }
-    if (may_overflow) HIP_TRY(hipMemsetAsync(plan->ovfcnt.p, 0, 4 * sizeof(uint32_t), s));   // no tier of this plan can overflow otherwise
+    // edge staging by the walk (tiers with one walk per wave): 512 bytes of scratch per row, bounded
+    static const int64_t stage_max = [] { const char *e = std::getenv("UGS_STAGE_MAX_MB"); return (e ? std::atoll(e) : 4096) << 20; }();
+    const bool stg = tc.first != UGS_TIER_S && row_count * (int64_t)(UGS_STAGE_ITEMS * sizeof(uint2)) <= stage_max;
+    plan->stg_valid = false;
+    if (stg) {
+        if (int rc = ensure(plan->stage, (size_t)row_count * UGS_STAGE_ITEMS * sizeof(uint2), plan->device)) return rc;
+        if (int rc = ensure(plan->staged, (size_t)row_count, plan->device)) return rc;
+        if (int rc = ensure(plan->ulist, (size_t)row_count * sizeof(int64_t), plan->device)) return rc;
+    }
+    if (may_overflow || stg) HIP_TRY(hipMemsetAsync(plan->ovfcnt.p, 0, 4 * sizeof(uint32_t), s));   // nothing else reads the counters
     uint32_t *cnt = static_cast<uint32_t *>(plan->ovfcnt.p);
     UgsWalkArgs a{};
     a.plan = plan->dev;
@@ -955,6 +972,12 @@ int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
     a.in_list = nullptr; a.in_count = nullptr;
     a.ovf_list = static_cast<int64_t *>(plan->ovf1.p);
     a.ovf_count = cnt + 0;
+    if (stg) {
+        a.stage = static_cast<uint2 *>(plan->stage.p); a.staged = static_cast<uint8_t *>(plan->staged.p);
+        a.ulist = static_cast<int64_t *>(plan->ulist.p); a.ucount = cnt + 3;
+        plan->stg_valid = true; plan->stg_nodes = d_nodes; plan->stg_row_begin = row_begin; plan->stg_row_count = row_count;
+        plan->stg_m = m_per_graph; plan->stg_k = k;
+    }
     HIP_TRY(ev_begin(plan, 0, s));
     HIP_TRY(ugs_launch_walk(a, tc.first, plan->cus, s, &plan->last_walk));
     HIP_TRY(ev_end(plan, s));
@@ -1026,6 +1049,11 @@ int ugs_plan_fill(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
     a.edge_index = d_edge_index; a.ld = ld; a.edge_src = d_edge_src;
     const TierChoice tc = choose_tier(plan, k);
     std::lock_guard<std::mutex> lk(plan->mu);
+    if (plan->stg_valid && plan->stg_nodes == d_nodes && plan->stg_row_begin == row_begin && plan->stg_row_count == row_count &&
+        plan->stg_m == m_per_graph && plan->stg_k == k) {
+        a.stage = static_cast<const uint2 *>(plan->stage.p); a.staged = static_cast<const uint8_t *>(plan->staged.p);
+        a.ulist = static_cast<const int64_t *>(plan->ulist.p); a.ucount = static_cast<const uint32_t *>(plan->ovfcnt.p) + 3;
+    }
     HIP_TRY(ev_begin(plan, 2, static_cast<hipStream_t>(stream)));
     HIP_TRY(ugs_launch_fill(a, tc.first != UGS_TIER_S, plan->cus, static_cast<hipStream_t>(stream), &plan->last_fill));
     HIP_TRY(ev_end(plan, static_cast<hipStream_t>(stream)));

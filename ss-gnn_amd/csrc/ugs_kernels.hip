@@ -636,10 +636,28 @@ template <int GS, int MAXPER> __device__ __forceinline__ uint32_t select_any(con
 // key word of the membership hash: vertex id (< 2^30) | kFresh (inserted by the chunk being processed) | kInS (sampled)
 constexpr uint32_t kKeyMask = 0x3FFFFFFFu, kFresh = 0x40000000u, kInS = 0x80000000u;
 
-template <int GS, class SP, bool ADD>
+// Edge staging (one walk per wave, LDS tiers): every entry of the scanned row that points into the sample IS an induced
+// edge between the new vertex (local index size-1) and an earlier member; its CSR position and the two local indices are
+// kept in a short LDS list and turned into the row's output items at the end of the walk (stage_flush).
+struct StageCtx {
+    uint4 *EL;               // [UGS_STAGE_ENTRIES]: x = CSR position, y = the member the entry points to, z = scanned vertex's local index
+    uint32_t ne;             // hits so far (may exceed the list: the row then goes to the row-reading fill kernel)
+    bool on;
+};
+
+template <int GS>
+__device__ __forceinline__ void stage_hits(StageCtx &sc, const Grp<GS> &g, bool in_s, uint32_t w, int64_t p, uint32_t size) {
+    const uint64_t im = g.ballot(in_s);
+    if (!im) return;
+    const uint32_t slot = sc.ne + (uint32_t)__popcll(im & g.lt_mask());
+    if (in_s && slot < UGS_STAGE_ENTRIES) sc.EL[slot] = make_uint4((uint32_t)p, w, size - 1u, 0u);
+    sc.ne += (uint32_t)__popcll(im);
+}
+
+template <int GS, class SP, bool ADD, bool STG>
 __device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, const UgsPlanDev &P, int64_t rbase, uint32_t v,
                                          uint32_t root_vi, uint32_t size, uint32_t &c, uint32_t &hcount,
-                                         uint32_t &ecount, int64_t r0, int64_t r1) {
+                                         uint32_t &ecount, int64_t r0, int64_t r1, StageCtx &sc) {
     for (int64_t base = r0; base < r1; base += GS) {
         const int64_t p = base + g.lane;
         bool cand = false;
@@ -682,6 +700,7 @@ __device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, c
             }
             if (inserted) ws.HK[slot] = w;                            // the chunk is over for this key: drop kFresh
             ecount += 2u * (uint32_t)__popcll(g.ballot(in_s && w != v)) + (uint32_t)__popcll(g.ballot(in_s && w == v));
+            if constexpr (STG) { if (sc.on) stage_hits<GS>(sc, g, in_s, w, p, size); }
             const uint64_t fm = g.ballot(first);
             const uint32_t nnew = (uint32_t)__popcll(fm);
             if (c + nnew > ws.cap) return false;
@@ -700,15 +719,48 @@ __device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, c
             }
             in_s = cand && seen != kEmpty && (seen & kKeyMask) == w && (seen & kInS) != 0u;
             ecount += 2u * (uint32_t)__popcll(g.ballot(in_s && w != v)) + (uint32_t)__popcll(g.ballot(in_s && w == v));
+            if constexpr (STG) { if (sc.on) stage_hits<GS>(sc, g, in_s, w, p, size); }
         }
     }
     return true;
 }
 
+// End of a complete walk: the <= 32 hits become the row's directed items (hit at position p of row s pointing to member i:
+// item s->i, and its mirror i->s unless i == s), ranked in the output order -- source index, then CSR position, and inside
+// one row CSR position order is edge-column order (the symmetrised CSR is built in column order; equal columns only for
+// the two identical entries of a self loop).  One lane per hit, the others' keys come through v_readlane as scalars.
+__device__ __forceinline__ void stage_flush(uint32_t ne, const Grp<64> &g, const uint32_t *SV, uint32_t k, uint4 en, uint32_t ecol, uint2 *out) {
+    const uint32_t lane = (uint32_t)g.lane;
+    const bool mine = lane < ne;
+    uint32_t ei = 0u;                                                         // local index of the member the hit points to
+    for (uint32_t j = 0; j < k; ++j) ei = (SV[j] == en.y) ? j : ei;
+    const uint32_t es = en.z;
+    uint32_t cr = 0u;                                                         // rank of the hit's column among the hits
+    for (uint32_t t = 0; t < ne; ++t) {
+        const uint32_t ct = g.bcast(ecol, (int)t);
+        cr += (ct < ecol || (ct == ecol && t < lane)) ? 1u : 0u;
+    }
+    const bool mirror = mine && ei != es;
+    const uint32_t ka = es * UGS_STAGE_ENTRIES + cr, kb = ei * UGS_STAGE_ENTRIES + cr;   // all keys are distinct
+    const uint32_t kk = (ka << 16) | kb;
+    uint32_t ra = 0u, rb = 0u;
+    for (uint32_t t = 0; t < ne; ++t) {
+        const uint32_t kt = g.bcast(kk, (int)t);
+        const uint32_t kat = kt >> 16, kbt = ((kt >> 21) == ((kt >> 5) & 0x7FFu)) ? 0xFFFFu : (kt & 0xFFFFu);   // no mirror: compares false
+        ra += (kat < ka ? 1u : 0u) + (kbt < ka ? 1u : 0u);
+        rb += (kat < kb ? 1u : 0u) + (kbt < kb ? 1u : 0u);
+    }
+    if (mine) out[ra] = make_uint2(ecol, es | (ei << 8));
+    if (mirror) out[rb] = make_uint2(ecol, ei | (es << 8));
+}
+
 // One walk.  Returns false on workspace overflow (the row is then redone by the next tier).
 template <int GS, class SP, int MAXPER>
 __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, const UgsWalkArgs &a, int64_t row_rel,
-                                        uint32_t *SV /* [UGS_KMAX] group-private */) {
+                                        uint32_t *SV /* [UGS_KMAX] group-private */, uint4 *EL /* [UGS_STAGE_ENTRIES] or null */) {
+    constexpr bool STG = GS == 64 && sizeof(typename SP::TW) == 4;             // one walk per wave, LDS workspace
+    StageCtx sc;
+    sc.EL = EL; sc.ne = 0u; sc.on = STG && a.stage != nullptr && EL != nullptr;
     const UgsPlanDev &P = a.plan;
     const int64_t row = a.row_begin + row_rel;
     int64_t gi, i;
@@ -719,7 +771,7 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
     int64_t *out = a.nodes + row_rel * k;
     if (gd.level < 0) {   // degenerate graph: m rows of -1, no edges (reference src/ugs_sampler_batch_extension.cpp:132-143)
         for (int j = g.lane; j < k; j += GS) out[j] = -1;
-        if (g.lane == 0) a.counts[row_rel] = 0;
+        if (g.lane == 0) { a.counts[row_rel] = 0; if (a.staged) a.staged[row_rel] = 0; }
         return true;
     }
     STAMP_DECL;
@@ -753,8 +805,8 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
     int nvalid = 0;           // leading stages of the order computation that are still valid
     STAMP_END(0);
     int64_t r0 = g.uni(P.rowptr[gd.rbase + root_v]), r1 = g.uni(P.rowptr[gd.rbase + root_v + 1]);
-    bool ok = (k > 1) ? scan_row<GS, SP, true>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, ecount, r0, r1)
-                      : scan_row<GS, SP, false>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, ecount, r0, r1);
+    bool ok = (k > 1) ? scan_row<GS, SP, true, STG>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, ecount, r0, r1, sc)
+                      : scan_row<GS, SP, false, STG>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, ecount, r0, r1, sc);
     STAMP_END(1);
     if (!ok) return false;
     for (int step = 1; step < k; ++step) {
@@ -802,15 +854,31 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
         size += 1;
         SP::sync();
         STAMP_END(3);
-        ok = (step < k - 1) ? scan_row<GS, SP, true>(ws, g, P, gd.rbase, w, root_vi, size, c, hcount, ecount, r0, r1)
-                            : scan_row<GS, SP, false>(ws, g, P, gd.rbase, w, root_vi, size, c, hcount, ecount, r0, r1);
+        ok = (step < k - 1) ? scan_row<GS, SP, true, STG>(ws, g, P, gd.rbase, w, root_vi, size, c, hcount, ecount, r0, r1, sc)
+                            : scan_row<GS, SP, false, STG>(ws, g, P, gd.rbase, w, root_vi, size, c, hcount, ecount, r0, r1, sc);
         STAMP_END(1);
         if (!ok) return false;
+    }
+    const uint32_t nedges = (size == (uint32_t)k) ? ecount : 0u;                // incomplete rows carry no edges (:219-223)
+    // staged hits: fetch their edge columns now, the row's epilogue below runs while the gather is in flight
+    bool flush = false;
+    uint4 en = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t ecol = 0u;
+    if constexpr (STG) {
+        flush = sc.on && nedges != 0u && sc.ne <= UGS_STAGE_ENTRIES;
+        if (flush && (uint32_t)g.lane < sc.ne) { en = sc.EL[g.lane]; ecol = (uint32_t)P.adjf[en.x].y; }
     }
     // nodes row: growth order, -1 padded (reference src/sampler.cpp:205-216, src/ugs_sampler_batch_extension.cpp:188-196)
     const int64_t off = gd.node_lo + a.extra_node_off;
     for (int j = g.lane; j < k; j += GS) out[j] = (j < (int)size) ? (int64_t)SV[j] + off : (int64_t)-1;
-    if (g.lane == 0) a.counts[row_rel] = (size == (uint32_t)k) ? ecount : 0u;   // incomplete rows carry no edges (:219-223)
+    if (g.lane == 0) a.counts[row_rel] = nedges;
+    if (a.staged) {                                                              // staging is on for this call
+        if constexpr (STG) { if (flush) stage_flush(sc.ne, g, SV, (uint32_t)k, en, ecol, a.stage + row_rel * UGS_STAGE_ITEMS); }
+        if (g.lane == 0) {
+            a.staged[row_rel] = flush ? 1 : 0;
+            if (!flush && nedges != 0u) a.ulist[atomicAdd(a.ucount, 1u)] = row_rel;
+        }
+    }
     STAMP_END(5);
     STAMP_FLUSH(g.lane);
     return true;
@@ -824,7 +892,8 @@ template <int CAP> struct TierCfg {
     static constexpr int BCAP_A = (BCAP + 3) & ~3;
     static constexpr int HS = CAP <= 64 ? 128 : (CAP <= 512 ? 512 : 4096);
     static constexpr int HLIMIT = CAP <= 512 && CAP > 64 ? HS / 8 * 7 : HS / 4 * 3;   // max distinct vertices a walk may have seen
-    static constexpr int WORDS = CAP /*D*/ + ORDW + BCAP_A /*TBL*/ + HS /*HK*/ + UGS_KMAX /*SV*/;
+    static constexpr int ELW = CAP > 64 ? 4 * UGS_STAGE_ENTRIES : 0;             // staged hits (one-walk-per-wave tiers)
+    static constexpr int WORDS = CAP /*D*/ + ORDW + BCAP_A /*TBL*/ + HS /*HK*/ + UGS_KMAX /*SV*/ + ELW;
 };
 
 // second launch-bounds argument = waves per SIMD the register allocation must allow.  CAP 448: 4 (<= 128 VGPRs, no spills).
@@ -849,6 +918,7 @@ __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 4 : (CAP <= 64 ? 
     ws.TBL = ws.ORD + Cfg::ORDW;
     ws.HK = ws.TBL + Cfg::BCAP_A;
     uint32_t *SV = ws.HK + Cfg::HS;
+    uint4 *EL = Cfg::ELW ? reinterpret_cast<uint4 *>(SV + UGS_KMAX) : nullptr;
     ws.cap = CAP;
     ws.hmask = Cfg::HS - 1;
     ws.hlimit = Cfg::HLIMIT;
@@ -856,7 +926,7 @@ __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 4 : (CAP <= 64 ? 
     const int64_t ngroups = (int64_t)gridDim.x * GROUPS;
     for (int64_t it = (int64_t)blockIdx.x * GROUPS + gib; it < total; it += ngroups) {
         const int64_t row_rel = a.in_list ? a.in_list[it] : it;
-        if (!do_walk<GS, LdsSpace, (CAP + GS - 1) / GS>(ws, g, a, row_rel, SV)) {
+        if (!do_walk<GS, LdsSpace, (CAP + GS - 1) / GS>(ws, g, a, row_rel, SV, EL)) {
             if (g.lane == 0) { uint32_t pos = atomicAdd(a.ovf_count, 1u); a.ovf_list[pos] = row_rel; }
         }
     }
@@ -881,7 +951,7 @@ __global__ __launch_bounds__(64) void ugs_walk_global(UgsWalkArgs a) {
     const int64_t total = a.in_list ? (int64_t)*a.in_count : a.row_count;
     for (int64_t it = blockIdx.x; it < total; it += gridDim.x) {
         const int64_t row_rel = a.in_list ? a.in_list[it] : it;
-        if (!do_walk<64, GlbSpace, 0>(ws, g, a, row_rel, SV)) {
+        if (!do_walk<64, GlbSpace, 0>(ws, g, a, row_rel, SV, nullptr)) {
             // cannot happen when gcap covers the graph's bound; mark the row so the host can report it
             if (g.lane == 0) { uint32_t pos = atomicAdd(a.ovf_count, 1u); a.ovf_list[pos] = row_rel; }
         }
@@ -987,7 +1057,9 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
     const UgsPlanDev &P = a.plan;
     const int k = a.k;
     const int64_t ngroups = (int64_t)gridDim.x * GROUPS;
-    for (int64_t row_rel = (int64_t)blockIdx.x * GROUPS + gib; row_rel < a.row_count; row_rel += ngroups) {
+    const int64_t todo = a.ulist ? (int64_t)*a.ucount : a.row_count;      // with staging: only the rows the walk could not stage
+    for (int64_t it = (int64_t)blockIdx.x * GROUPS + gib; it < todo; it += ngroups) {
+        const int64_t row_rel = a.ulist ? a.ulist[it] : it;
         const int64_t e0 = a.edge_ptr[row_rel], e1 = a.edge_ptr[row_rel + 1];
         if (e1 == e0) continue;                               // incomplete or edgeless row
         const int64_t row = a.row_begin + row_rel;
@@ -1204,13 +1276,56 @@ hipError_t ugs_launch_scan(const uint32_t *counts, int64_t rows, int64_t *edge_p
     return hipGetLastError();
 }
 
+// Rows staged by the walk: the items are already in output order; 16 lanes per row apply the endpoint numbering of the mode
+// (reference src/sampler.cpp:258-281) and write the three output arrays.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void ugs_fill_staged(UgsFillArgs a) {
+    constexpr int GS = 16, GROUPS = BLOCK / GS;
+    const int lane = (int)threadIdx.x & (GS - 1), gib = (int)threadIdx.x / GS;
+    const UgsPlanDev &P = a.plan;
+    const int k = a.k;
+    const int64_t ngroups = (int64_t)gridDim.x * GROUPS;
+    for (int64_t row_rel = (int64_t)blockIdx.x * GROUPS + gib; row_rel < a.row_count; row_rel += ngroups) {
+        if (!a.staged[row_rel]) continue;
+        const int64_t e0 = a.edge_ptr[row_rel];
+        const int n = (int)(a.edge_ptr[row_rel + 1] - e0);
+        const uint2 *items = a.stage + row_rel * UGS_STAGE_ITEMS;
+        const int64_t *nrow = a.nodes + row_rel * k;
+        int64_t i = 0;
+        if (a.mode == 1) {
+            const int64_t row = a.row_begin + row_rel;
+            i = (P.num_graphs == 1) ? row : row % a.m;
+        }
+        for (int t = lane; t < n && t < UGS_STAGE_ITEMS; t += GS) {
+            const uint2 x = items[t];
+            const int j = (int)(x.y & 0xFFu), l = (int)(x.y >> 8);
+            int64_t uf, vf;
+            if (a.mode == 0) { uf = j; vf = l; }
+            else if (a.mode == 1) { uf = i * k + j; vf = i * k + l; }
+            else { uf = nrow[j]; vf = nrow[l]; }
+            a.edge_index[e0 + t] = uf;
+            a.edge_index[a.ld + e0 + t] = vf;
+            a.edge_src[e0 + t] = (int64_t)(int32_t)x.x;
+        }
+    }
+}
+
 hipError_t ugs_launch_fill(const UgsFillArgs &a, int wide, int cus, hipStream_t s, UgsLaunchInfo *info) {
     if (a.row_count <= 0) return hipSuccess;
     if (cus <= 0) cus = 256;
+    if (a.stage) {
+        constexpr int BLOCK = 256, GROUPS = 16;
+        int64_t grid = (a.row_count + GROUPS - 1) / GROUPS;
+        if (grid > (int64_t)cus * 32) grid = (int64_t)cus * 32;
+        hipLaunchKernelGGL((ugs_fill_staged<BLOCK>), dim3((unsigned)grid), dim3(BLOCK), 0, s, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     if (wide) {
         constexpr int BLOCK = 256, GROUPS = 4;
         int64_t grid = (a.row_count + GROUPS - 1) / GROUPS;
         if (grid > (int64_t)cus * 8) grid = (int64_t)cus * 8;
+        if (a.ulist && grid > cus) grid = cus;                 // leftovers of a staged call: few rows, length known on the device only
         hipLaunchKernelGGL((ugs_fill<64, BLOCK>), dim3((unsigned)grid), dim3(BLOCK), 0, s, a);
         if (info) { info->name = "ugs_fill<64>"; info->grid = (int)grid; info->block = BLOCK; info->lds_bytes = GROUPS * UGS_KMAX * 20; }
     } else {
