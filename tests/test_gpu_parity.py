@@ -326,3 +326,63 @@ print("OK")
 '''
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=150)
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("tier", ["1", "2"])
+def test_edges_staged_by_the_walk_and_the_leftover_rows(tier, product, orc, monkeypatch):
+    """64-lane tiers: the walk stages up to 32 induced-edge hits per row and the fill kernel expands them; denser rows go
+    to the row-reading fill kernel through a list.  Dense graphs with large k (hundreds of induced edges), multigraphs with
+    repeated columns and self loops, every numbering mode."""
+    monkeypatch.setenv("UGS_FORCE_TIER", tier)
+    rng = random.Random(100 + int(tier))
+    calls = []
+    for n, p, k, m, mode in [(24, 0.9, 12, 60, "sample"), (40, 0.5, 9, 80, "graph"), (60, 0.25, 8, 100, "global"), (18, 1.0, 10, 40, "sample")]:
+        e = [(u, v) for u in range(n) for v in range(u + 1, n) if rng.random() < p]
+        e += [(v, u) for u, v in e[: len(e) // 2]]                        # both directions of half the edges: repeated pairs
+        e += [(rng.randrange(n),) * 2 for _ in range(4)]                  # self loops
+        e += e[:7]                                                        # repeated columns
+        rng.shuffle(e)
+        ei = np.array(e, dtype=np.int64).T.reshape(2, -1).copy()
+        calls.append(dict(fn="sample_batch", edge_index=ei, ptr=np.array([0, n], dtype=np.int64), m=m, k=k, mode=mode, seed=21))
+    # rows around the 32-hit limit inside ONE call (sparse and dense graphs in a batch)
+    cols, ptr = [], [0]
+    for n, p in [(30, 0.15), (14, 1.0), (30, 0.5), (12, 0.8)]:
+        off = ptr[-1]
+        cols += [(u + off, v + off) for u in range(n) for v in range(u + 1, n) if rng.random() < p]
+        ptr.append(off + n)
+    ei = np.array(cols, dtype=np.int64).T.reshape(2, -1).copy()
+    for mode in ("sample", "graph", "global"):
+        calls.append(dict(fn="sample_batch", edge_index=ei, ptr=np.array(ptr, dtype=np.int64), m=50, k=9, mode=mode, seed=5))
+    _same(calls, product, orc, f"staged edges, tier {tier}")
+
+
+def test_fill_after_another_walk_reads_the_rows_again(monkeypatch):
+    """The staging belongs to the LAST walk of a plan: walk A, walk B, fill A, fill B must still give A's and B's edges."""
+    import torch
+    import ugs_sampler
+    monkeypatch.setenv("UGS_FORCE_TIER", "1")
+    rng = random.Random(3)
+    n, k, m = 50, 6, 200
+    e = [(u, v) for u in range(n) for v in range(u + 1, n) if rng.random() < 0.2]
+    ei_t = torch.tensor(e, dtype=torch.long).t().contiguous()
+    ptr_t = torch.tensor([0, n], dtype=torch.long)
+    ugs_sampler.clear_cache()
+    want_a = ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode="sample", seed=1)
+    want_b = ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode="sample", seed=2)
+    plan = ugs_sampler.Plan.from_batch(ei_t, ptr_t, k)
+    na, pa, ta = plan.walk(m, "sample", 1)
+    nb, pb, tb = plan.walk(m, "sample", 2)
+    ea, sa = plan.fill(m, na, pa, ta, "sample")          # staging now holds B's rows: A is filled from the adjacency rows
+    eb, sb = plan.fill(m, nb, pb, tb, "sample")          # B: expanded from the staging
+    for got, want in ((ea, want_a[1]), (sa, want_a[4]), (eb, want_b[1]), (sb, want_b[4]), (na, want_a[0]), (nb, want_b[0])):
+        assert torch.equal(got.cpu(), want)
+    # same nodes buffer reused by a later walk, partial row range
+    nodes = torch.empty((m, k), dtype=torch.int64, device="cuda")
+    eptr = torch.empty((m + 1,), dtype=torch.int64, device="cuda")
+    plan.walk(m, "sample", 1, out=(nodes, eptr))
+    n2, p2, t2 = plan.walk(m, "sample", 2, row_begin=10, row_count=50, out=(nodes[:50], eptr[:51]))
+    e2, s2 = plan.fill(m, n2, p2, t2, "sample", row_begin=10)
+    lo, hi = int(want_b[2][10]), int(want_b[2][60])
+    assert torch.equal(e2.cpu(), want_b[1][:, lo:hi]) and torch.equal(s2.cpu(), want_b[4][lo:hi])
+    plan.close()
+    ugs_sampler.clear_cache()
