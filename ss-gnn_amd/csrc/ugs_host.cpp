@@ -1107,7 +1107,7 @@ struct ugs_job {
     PoolBuf nodes, eptr;
     // epsilon_uniform path
     bool eps = false;
-    void *eps_blob = nullptr;
+    PoolBuf eps_blob;                  // pooled: hipMalloc/hipFree per call cost milliseconds once the process holds large plans
     UgsEpsLaunch eps_l{};
     PoolBuf eps_counts, eps_scantmp;
 };
@@ -1117,7 +1117,7 @@ void free_job(ugs_job *j) {
     if (!j) return;
     pool_put(j->nodes); pool_put(j->eptr);
     pool_put(j->eps_counts); pool_put(j->eps_scantmp);
-    if (j->eps_blob) (void)hipFree(j->eps_blob);
+    pool_put(j->eps_blob);
     plan_unref(j->plan);
     delete j;
 }
@@ -1277,11 +1277,10 @@ int ugs_eps_sample_batch_begin(const int64_t *edge_index, int64_t row_stride, in
     j->dc = dc; j->eps = true; j->batch = true; j->m = m_per_graph; j->k = k; j->mode = mode; j->G = G;
     j->rows = G * (int64_t)m_per_graph;
     auto bail = [&](int rc) { free_job(j); return rc; };
-    hipError_t e = hipMalloc(&j->eps_blob, total);
-    if (e != hipSuccess) return bail(fail_hip(e, "hipMalloc"));
-    e = hipMemcpy(j->eps_blob, host.data(), total, hipMemcpyHostToDevice);
+    if (int rc = pool_get(total, dc.id, j->eps_blob)) return bail(rc);
+    hipError_t e = hipMemcpy(j->eps_blob.p, host.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) return bail(fail_hip(e, "hipMemcpy"));
-    char *base = static_cast<char *>(j->eps_blob);
+    char *base = static_cast<char *>(j->eps_blob.p);
     if (int rc = pool_get((size_t)std::max<int64_t>(j->rows * k, 1) * sizeof(int64_t), dc.id, j->nodes)) return bail(rc);
     if (int rc = pool_get((size_t)(j->rows + 1) * sizeof(int64_t), dc.id, j->eptr)) return bail(rc);
     if (int rc = pool_get((size_t)std::max<int64_t>(j->rows, 1) * sizeof(uint32_t), dc.id, j->eps_counts)) return bail(rc);
