@@ -571,54 +571,90 @@ __device__ __forceinline__ uint32_t stage_final(const Work<LdsSpace> &ws, const 
 
 // LDS tiers: iteration-order selection with the register-resident stages; `nvalid` = number of leading stages whose
 // materialised order is still valid (the candidates they cover did not change since they were computed).
+// An LDS tier only ever touches the first NST+1 entries of the bucket chain, so the stage index is a template parameter:
+// B, the multiply-shift constants and the order-array offsets are immediates (no scalar loads from the chain table, no
+// waits on them), the elements-per-lane variant of a materialising stage is fixed at compile time, and a final stage only
+// carries the variants its candidate range (B[stage-1], min(B[stage], CAP)] can need.
+constexpr int nj_of(int per) { return per <= 1 ? 1 : per <= 3 ? 3 : per <= 5 ? 5 : per <= 7 ? 7 : per <= 9 ? 9 : per <= 13 ? 13 : per <= 17 ? 17 : 33; }
+constexpr int nst_of(int cap) { return cap <= 64 ? 3 : (cap <= 512 ? 5 : 7); }       // stages that are ever materialised
+
+template <int STAGE> struct ChainAt {
+    static constexpr uint32_t B = kChainHost[STAGE], M = cmagic(kChainHost[STAGE]), S = (uint32_t)clog2(kChainHost[STAGE]) - 1u;
+    static constexpr uint32_t O = ord_words_before(STAGE);
+    static constexpr uint32_t NOLD = STAGE ? kChainHost[STAGE ? STAGE - 1 : 0] : 0u;
+    static constexpr uint32_t OOLD = STAGE ? ord_words_before(STAGE ? STAGE - 1 : 0) : 0u;
+};
+
+template <int GS, int MAXPER, int STAGE>
+__device__ __forceinline__ void mat_at(const Work<LdsSpace> &ws, const Grp<GS> &g) {
+    using C = ChainAt<STAGE>;
+    const uint32_t *OLD = STAGE ? ws.ORD + C::OOLD : ws.D;
+    uint32_t *NEW = ws.ORD + C::O;
+    constexpr int per = (int)((C::B + GS - 1) / GS);                          // these stages are full: L == B
+    if constexpr (GS == 64 && per <= 1) stage_mat_reg(ws, g, OLD, NEW, C::NOLD, C::B, C::M, C::S);
+    else if constexpr (GS == 64 && per <= 2) stage_mat_reg2(ws, g, OLD, NEW, C::NOLD, C::B, C::M, C::S);
+    else stage_mat<GS, nj_of(per)>(ws, g, OLD, NEW, C::NOLD, C::B, C::M, C::S);
+}
+
+template <int GS, int MAXPER, int STAGE>
+__device__ __forceinline__ uint32_t final_at(const Work<LdsSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel) {
+    using C = ChainAt<STAGE>;
+    const uint32_t *OLD = STAGE ? ws.ORD + C::OOLD : ws.D;
+    constexpr uint32_t CAP = (uint32_t)(MAXPER * GS);
+    constexpr int pmin = (int)((C::NOLD + 1u + GS - 1) / GS), pmax = (int)(((C::B < CAP ? C::B : CAP) + GS - 1) / GS);
+    const int per = (int)((c + GS - 1) / GS);
+    // a variant serving per in [LO, HI] exists only if the stage's range meets it; the last one that does needs no test
+#define UGS_FINAL_CASE(LO, HI, CALL) if constexpr (pmin <= (HI) && pmax >= (LO)) { if (pmax <= (HI) || per <= (HI)) return CALL; }
+    if constexpr (GS == 64) {
+        UGS_FINAL_CASE(1, 1, stage_final_reg(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel))
+        UGS_FINAL_CASE(2, 2, stage_final_reg2(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel))
+        UGS_FINAL_CASE(3, 3, (stage_final<GS, 3>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
+    } else {
+        UGS_FINAL_CASE(1, 1, (stage_final<GS, 1>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
+        UGS_FINAL_CASE(2, 3, (stage_final<GS, 3>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
+    }
+    UGS_FINAL_CASE(4, 5, (stage_final<GS, 5>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
+    UGS_FINAL_CASE(6, 7, (stage_final<GS, 7>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
+    UGS_FINAL_CASE(8, 9, (stage_final<GS, 9>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
+    UGS_FINAL_CASE(10, 11, (stage_final<GS, 11>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
+    UGS_FINAL_CASE(12, 13, (stage_final<GS, 13>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
+    UGS_FINAL_CASE(14, 17, (stage_final<GS, 17>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
+    UGS_FINAL_CASE(18, 1 << 20, (stage_final<GS, 33>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
+#undef UGS_FINAL_CASE
+    return 0u;
+}
+
+template <int GS, int MAXPER, int STAGE, int NST>
+__device__ __forceinline__ void materialise_from(const Work<LdsSpace> &ws, const Grp<GS> &g, int fs, int &nvalid) {
+    if constexpr (STAGE < NST) {
+        if (nvalid <= STAGE && STAGE < fs) { mat_at<GS, MAXPER, STAGE>(ws, g); nvalid = STAGE + 1; }
+        materialise_from<GS, MAXPER, STAGE + 1, NST>(ws, g, fs, nvalid);
+    }
+}
+
+template <int GS, int MAXPER, int STAGE, int NST>
+__device__ __forceinline__ uint32_t final_from(const Work<LdsSpace> &ws, const Grp<GS> &g, int fs, uint32_t c, uint32_t rsel) {
+    if constexpr (STAGE < NST) {
+        if (fs == STAGE) return final_at<GS, MAXPER, STAGE>(ws, g, c, rsel);
+        return final_from<GS, MAXPER, STAGE + 1, NST>(ws, g, fs, c, rsel);
+    } else {
+        return final_at<GS, MAXPER, NST>(ws, g, c, rsel);
+    }
+}
+
+template <int NST> __device__ __forceinline__ int chain_index_below(uint32_t x) {     // number of the first NST chain values < x
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) n += (kChainHost[i] < x) ? 1 : 0;
+    return n;
+}
+
 template <int GS, int MAXPER>
 __device__ __forceinline__ uint32_t select_lds(const Work<LdsSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel, int &nvalid) {
-    int fs = 0;
-    while (fs < kChainLen - 1 && d_chain.B[fs] < c) ++fs;
-    for (int stage = nvalid < fs ? nvalid : fs; stage < fs; ++stage) {      // stages that are materialised (and then cached)
-        const uint32_t B = d_chain.B[stage], M = d_chain.M[stage], S = d_chain.S[stage];
-        const uint32_t *OLD = stage ? ws.ORD + d_chain.O[stage - 1] : ws.D;
-        uint32_t *NEW = ws.ORD + d_chain.O[stage];
-        const uint32_t n_old = stage ? d_chain.B[stage - 1] : 0u;
-        const uint32_t per = (B + GS - 1) / GS;                             // these stages are full: L == B
-        if constexpr (GS == 64) {
-            if (per <= 1) { stage_mat_reg(ws, g, OLD, NEW, n_old, B, M, S); nvalid = stage + 1; continue; }
-            if (per <= 2) { stage_mat_reg2(ws, g, OLD, NEW, n_old, B, M, S); nvalid = stage + 1; continue; }
-        }
-        if (per <= 1) stage_mat<GS, 1>(ws, g, OLD, NEW, n_old, B, M, S);
-        else if (per <= 3) stage_mat<GS, 3>(ws, g, OLD, NEW, n_old, B, M, S);
-        else if (per <= 5) stage_mat<GS, 5>(ws, g, OLD, NEW, n_old, B, M, S);
-        else if (per <= 7 || MAXPER <= 7) stage_mat<GS, 7>(ws, g, OLD, NEW, n_old, B, M, S);
-        else if (per <= 9 || MAXPER <= 9) stage_mat<GS, 9>(ws, g, OLD, NEW, n_old, B, M, S);
-        else if constexpr (MAXPER > 9) {
-            if (per <= 13) stage_mat<GS, 13>(ws, g, OLD, NEW, n_old, B, M, S);
-            else if (per <= 17 || MAXPER <= 17) stage_mat<GS, 17>(ws, g, OLD, NEW, n_old, B, M, S);
-            else if constexpr (MAXPER > 17) stage_mat<GS, 33>(ws, g, OLD, NEW, n_old, B, M, S);
-        }
-        nvalid = stage + 1;
-    }
-    {
-        const uint32_t B = d_chain.B[fs], M = d_chain.M[fs], S = d_chain.S[fs];
-        const uint32_t *OLD = fs ? ws.ORD + d_chain.O[fs - 1] : ws.D;
-        const uint32_t n_old = fs ? d_chain.B[fs - 1] : 0u;
-        const uint32_t per = (c + GS - 1) / GS;
-        if constexpr (GS == 64) {
-            if (per <= 1) return stage_final_reg(ws, g, OLD, n_old, c, B, M, S, rsel);
-            if (per <= 2) return stage_final_reg2(ws, g, OLD, n_old, c, B, M, S, rsel);
-        }
-        if (per <= 1) return stage_final<GS, 1>(ws, g, OLD, n_old, c, B, M, S, rsel);
-        else if (per <= 3) return stage_final<GS, 3>(ws, g, OLD, n_old, c, B, M, S, rsel);
-        else if (per <= 5) return stage_final<GS, 5>(ws, g, OLD, n_old, c, B, M, S, rsel);
-        else if (per <= 7 || MAXPER <= 7) return stage_final<GS, 7>(ws, g, OLD, n_old, c, B, M, S, rsel);
-        else if (per <= 9 || MAXPER <= 9) return stage_final<GS, 9>(ws, g, OLD, n_old, c, B, M, S, rsel);
-        else if constexpr (MAXPER > 9) {
-            if (per <= 11) return stage_final<GS, 11>(ws, g, OLD, n_old, c, B, M, S, rsel);
-            else if (per <= 13) return stage_final<GS, 13>(ws, g, OLD, n_old, c, B, M, S, rsel);
-            else if (per <= 17 || MAXPER <= 17) return stage_final<GS, 17>(ws, g, OLD, n_old, c, B, M, S, rsel);
-            else if constexpr (MAXPER > 17) return stage_final<GS, 33>(ws, g, OLD, n_old, c, B, M, S, rsel);
-        }
-    }
-    return 0u;
+    constexpr int NST = nst_of(MAXPER * GS);
+    const int fs = chain_index_below<NST>(c);                                 // the final stage: first chain value >= c
+    materialise_from<GS, MAXPER, 0, NST>(ws, g, fs, nvalid);
+    return final_from<GS, MAXPER, 0, NST>(ws, g, fs, c, rsel);
 }
 
 template <int GS, int MAXPER> __device__ __forceinline__ uint32_t select_any(const Work<LdsSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel, int &nvalid) {
@@ -841,7 +877,12 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
         }
         {   // stages whose candidates all precede position q keep their order
             int keep = 0;
-            while (keep < nvalid && d_chain.B[keep] <= q) ++keep;
+            if constexpr (sizeof(typename SP::TW) == 4) {                     // LDS tiers: the chain values are immediates
+                keep = chain_index_below<nst_of(MAXPER * GS)>(q + 1u);        // number of B[i] <= q
+                keep = keep < nvalid ? keep : nvalid;
+            } else {
+                while (keep < nvalid && d_chain.B[keep] <= q) ++keep;
+            }
             nvalid = keep;
         }
         c -= 1;
