@@ -548,15 +548,14 @@ __device__ __forceinline__ uint32_t stage_final(const Work<LdsSpace> &ws, const 
     const uint64_t hm = g.ballot(hit);
     const int hsrc = hm ? (__ffsll((long long)hm) - 1) : 0;
     const uint32_t bstar = g.bcast(hb, hsrc), off = g.bcast(ho, hsrc);
-    // members of that bucket are visited in DESCENDING position: the answer has exactly `off` members above it
-    const uint64_t above = (g.lane == GS - 1) ? 0ull : ((~0ull << (g.lane + 1)) & ((GS == 64) ? ~0ull : ((1ull << (GS & 63)) - 1ull)));
+    // members of that bucket are visited in DESCENDING position: the answer has exactly `off` members above it.  Members in
+    // higher lanes: the lane's own member count, suffix-summed over the lanes by ONE scan (not one ballot per element slot)
     bool cand[NJ];
-    uint32_t higher = 0u;
+    uint32_t own = 0u;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        cand[j] = valid[j] && bk[j] == bstar;
-        higher += (uint32_t)__popcll(g.ballot(cand[j]) & above);
-    }
+    for (int j = 0; j < NJ; ++j) { cand[j] = valid[j] && bk[j] == bstar; own += cand[j] ? 1u : 0u; }
+    const uint32_t oincl = g.prefix_incl(own);
+    const uint32_t higher = g.last(oincl) - oincl;
     bool have = false;
     uint32_t mine = 0u, own_above = 0u;
 #pragma unroll
