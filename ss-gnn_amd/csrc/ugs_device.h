@@ -111,6 +111,8 @@ struct UgsLaunchInfo {
 enum { UGS_TIER_S = 0 /* cap 64, 8 lanes */, UGS_TIER_M = 1 /* cap 448, 64 lanes */, UGS_TIER_L = 2 /* cap 2048, 64 lanes */,
        UGS_TIER_G = 3 /* global-memory workspace, 64 lanes */ };
 static const int UGS_TIER_CAP[3] = {64, 448, 2048};
+static constexpr int UGS_TIER_LANES[3] = {8, 64, 64};              // lanes per walk
+static constexpr int UGS_TIER_HASH_LIMIT[3] = {96, 448, 3072};     // TierCfg<CAP>::HLIMIT (static_assert in ugs_kernels.hip)
 
 hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int device_cus, hipStream_t s, UgsLaunchInfo *info);
 hipError_t ugs_launch_scan(const uint32_t *counts, int64_t rows, int64_t *edge_ptr, int64_t *block_tmp, hipStream_t s);

@@ -690,8 +690,13 @@ TierChoice choose_tier(ugs_plan *p, int k) {
     else if (est <= UGS_TIER_CAP[1] || bound <= UGS_TIER_CAP[1]) t.first = UGS_TIER_M;
     else t.first = UGS_TIER_L;
     if (const char *e = std::getenv("UGS_FORCE_TIER")) { int f = std::atoi(e); if (f >= 0 && f <= 2) t.first = f; }
-    t.second_L = t.first < UGS_TIER_L && bound > UGS_TIER_CAP[t.first];
-    t.third_G = bound > UGS_TIER_CAP[2];
+    // A tier hands a walk on when its candidate list would overflow (bound > CAP) OR when its hash-table guard trips:
+    // `vertices seen + candidate lanes of the chunk > hash limit`, which is conservative (the lanes need not be new).  A walk
+    // has seen at most bound + 1 vertices, so the guard can trip as soon as bound + 1 + lanes-per-walk exceeds the limit --
+    // for the 448-candidate tier (limit 448, 64 lanes) already from bound 384.
+    auto may_hand_on = [&](int tier) { return bound > UGS_TIER_CAP[tier] || bound + 1 + UGS_TIER_LANES[tier] > UGS_TIER_HASH_LIMIT[tier]; };
+    t.second_L = t.first < UGS_TIER_L && may_hand_on(t.first);
+    t.third_G = may_hand_on(UGS_TIER_L);
     p->tiers[k] = t;
     return t;
 }

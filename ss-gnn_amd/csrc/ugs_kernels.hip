@@ -932,6 +932,7 @@ template <int CAP> struct TierCfg {
     static constexpr int BCAP_A = (BCAP + 3) & ~3;
     static constexpr int HS = CAP <= 64 ? 128 : (CAP <= 512 ? 512 : 4096);
     static constexpr int HLIMIT = CAP <= 512 && CAP > 64 ? HS / 8 * 7 : HS / 4 * 3;   // max distinct vertices a walk may have seen
+    static_assert(HLIMIT == UGS_TIER_HASH_LIMIT[CAP <= 64 ? 0 : (CAP <= 512 ? 1 : 2)], "host tier logic (choose_tier) relies on this limit");
     static constexpr int ELW = CAP > 64 ? 4 * UGS_STAGE_ENTRIES : 0;             // staged hits (one-walk-per-wave tiers)
     static constexpr int WORDS = CAP /*D*/ + ORDW + BCAP_A /*TBL*/ + HS /*HK*/ + UGS_KMAX /*SV*/ + ELW;
 };
@@ -967,7 +968,7 @@ __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 4 : (CAP <= 64 ? 
     for (int64_t it = (int64_t)blockIdx.x * GROUPS + gib; it < total; it += ngroups) {
         const int64_t row_rel = a.in_list ? a.in_list[it] : it;
         if (!do_walk<GS, LdsSpace, (CAP + GS - 1) / GS>(ws, g, a, row_rel, SV, EL)) {
-            if (g.lane == 0) { uint32_t pos = atomicAdd(a.ovf_count, 1u); a.ovf_list[pos] = row_rel; }
+            if (g.lane == 0 && a.ovf_list) { uint32_t pos = atomicAdd(a.ovf_count, 1u); a.ovf_list[pos] = row_rel; }
         }
     }
 }
@@ -993,7 +994,7 @@ __global__ __launch_bounds__(64) void ugs_walk_global(UgsWalkArgs a) {
         const int64_t row_rel = a.in_list ? a.in_list[it] : it;
         if (!do_walk<64, GlbSpace, 0>(ws, g, a, row_rel, SV, nullptr)) {
             // cannot happen when gcap covers the graph's bound; mark the row so the host can report it
-            if (g.lane == 0) { uint32_t pos = atomicAdd(a.ovf_count, 1u); a.ovf_list[pos] = row_rel; }
+            if (g.lane == 0 && a.ovf_list) { uint32_t pos = atomicAdd(a.ovf_count, 1u); a.ovf_list[pos] = row_rel; }
         }
     }
 }
