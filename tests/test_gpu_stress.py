@@ -50,10 +50,11 @@ def test_random_batches_under_every_first_tier(tier, monkeypatch):
         monkeypatch.setenv("UGS_FORCE_TIER", tier)
     rng = random.Random(2000 + (int(tier) if tier else 7))
     ugs_sampler.clear_cache()
-    for it in range(120):
+    cache = oracle.Cache()        # the reference's LRU lives across calls (its key ignores k): same call history on both sides
+    for it in range(300):
         ei, ptr, m, k, mode, seed = _case(rng)
         try:
-            want = oracle.sample_batch(ei, ptr, m, k, mode, seed)
+            want = oracle.sample_batch(ei, ptr, m, k, mode, seed, cache)
         except oracle.OracleError as ex:
             want = ex
         try:
@@ -68,3 +69,4 @@ def test_random_batches_under_every_first_tier(tier, monkeypatch):
         for g, w in zip(got, want):
             assert np.array_equal(g.numpy(), np.asarray(w)), what
     ugs_sampler.clear_cache()
+    cache.close()
