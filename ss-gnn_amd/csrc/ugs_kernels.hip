@@ -6,7 +6,7 @@
 //                 the relaxed viable list (src/sampler.cpp:163-173), k-1 growth steps (rand_grow, src/sampler.cpp:36-85),
 //                 per-row induced-edge COUNT; rows come out as nodes[row,k] (-1 padded)
 //   scan kernels: exclusive prefix sum of the counts -> edge_ptr
-//   fill kernel : induced edges of every complete row in the reference's order (vertex j, then CSR position p;
+//   fill kernels: induced edges of every complete row in the reference's order (vertex j, then CSR position p;
 //                 src/sampler.cpp:232-243) with the endpoint numbering of the requested mode (src/sampler.cpp:258-281)
 //
 // How (MI355X-first, nothing translated from the reference's std::unordered_set code):
@@ -24,10 +24,15 @@
 //     the members above it; rank = start + count (stage_mat).  Every stage keeps its own order array, valid across
 //     growth steps while the removed candidate lies behind the prefix it covers.  The last stage materialises nothing:
 //     the bucket holding position rng % |cut| is found by the scan and the element inside it by ballots (stage_final).
+//     Stages of up to 128 elements (one walk per wave) never touch the bucket table: a radix pass of ballots gives every
+//     lane the mask of its bucket-mates and popcounts do the rest (rank_in_registers / rank2_in_registers).  In the LDS
+//     tiers the stage index is a template parameter, so the chain constants are immediates (mat_at / final_at).
 //     (The global-memory fallback tier keeps the simpler "peel round" formulation, select_in_order.)
 //   * the neighbour's order rank is stored next to the neighbour id in HBM (int2 adjacency), so the suffix filter is
 //     free; root records pack the alias row and both candidate root vertices in 24 bytes.
-//   * ballot + popcount prefix sums compact new candidates into D and (fill kernel) edges into the output.
+//   * ballot + popcount prefix sums compact new candidates into D and (row-reading fill kernel) edges into the output.
+//   * the 64-lane tiers stage the induced edges they meet while scanning rows (stage_hits / stage_flush): the fill kernel
+//     of those rows is a plain expand (ugs_fill_staged); rows that do not fit are listed for the row-reading ugs_fill.
 #include "ugs_device.h"
 #include <cstdlib>
 
