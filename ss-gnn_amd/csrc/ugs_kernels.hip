@@ -1298,7 +1298,7 @@ hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, hipStream_t 
     case UGS_TIER_S: return launch_lds<8, 64, 256>(a, cus, 2, s, info, "ugs_walk_lds<8,64>");
     // one walk per wave: two walks per wave (GS 32) measured 26.4 ms vs 18.7 ms per 1M walks on C5 (two chunks per row)
     case UGS_TIER_M: return launch_lds<64, 448, 64>(a, cus, 16, s, info, "ugs_walk_lds<64,448>");   // 4 waves/SIMD resident (registers)
-    case UGS_TIER_L: return launch_lds<64, 2048, 64>(a, cus, 2, s, info, "ugs_walk_lds<64,2048>");
+    case UGS_TIER_L: return launch_lds<64, 2048, 64>(a, cus, 3, s, info, "ugs_walk_lds<64,2048>");   // 43 KB of LDS per walk: 3 fit
     default: {
         int64_t grid = a.gws_words_per_group > 0 ? a.gws_groups : 0;
         if (grid < 1) return hipErrorInvalidValue;
