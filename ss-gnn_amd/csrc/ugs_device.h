@@ -108,11 +108,12 @@ struct UgsLaunchInfo {
 };
 
 // tiers of the walk kernel: candidate-set capacity held in LDS per walk, lanes per walk
-enum { UGS_TIER_S = 0 /* cap 64, 8 lanes */, UGS_TIER_M = 1 /* cap 448, 64 lanes */, UGS_TIER_L = 2 /* cap 2048, 64 lanes */,
-       UGS_TIER_G = 3 /* global-memory workspace, 64 lanes */ };
-static const int UGS_TIER_CAP[3] = {64, 448, 2048};
-static constexpr int UGS_TIER_LANES[3] = {8, 64, 64};              // lanes per walk
-static constexpr int UGS_TIER_HASH_LIMIT[3] = {96, 448, 3072};     // TierCfg<CAP>::HLIMIT (static_assert in ugs_kernels.hip)
+enum { UGS_TIER_S = 0 /* cap 64, 8 lanes */, UGS_TIER_M = 1 /* cap 448, 64 lanes */, UGS_TIER_X = 2 /* cap 1024, 64 lanes */,
+       UGS_TIER_L = 3 /* cap 2048, 64 lanes */, UGS_TIER_G = 4 /* global-memory workspace, 64 lanes */ };
+#define UGS_LDS_TIERS 4
+static constexpr int UGS_TIER_CAP[UGS_LDS_TIERS] = {64, 448, 1024, 2048};
+static constexpr int UGS_TIER_LANES[UGS_LDS_TIERS] = {8, 64, 64, 64};             // lanes per walk
+static constexpr int UGS_TIER_HASH_LIMIT[UGS_LDS_TIERS] = {96, 448, 1536, 3072};  // TierCfg<CAP>::HLIMIT (static_assert in ugs_kernels.hip)
 
 hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int device_cus, hipStream_t s, UgsLaunchInfo *info);
 hipError_t ugs_launch_scan(const uint32_t *counts, int64_t rows, int64_t *edge_ptr, int64_t *block_tmp, hipStream_t s);

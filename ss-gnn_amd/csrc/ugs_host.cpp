@@ -406,7 +406,7 @@ void pool_put(PoolBuf &b) {
 // ---------------------------------------------------------------------------------------------------------------
 // plans
 // ---------------------------------------------------------------------------------------------------------------
-struct TierChoice { int first = UGS_TIER_S; bool second_L = false; bool third_G = false; int64_t bound = 0; };
+struct TierChoice { int first = UGS_TIER_S; int second = -1 /* LDS tier that redoes the rows the first one hands on */; bool third_G = false; int64_t bound = 0; };
 
 struct ugs_plan {
     int device = -1, cus = 256;
@@ -686,17 +686,23 @@ TierChoice choose_tier(ugs_plan *p, int k) {
     }
     TierChoice t;
     t.bound = bound;
-    if (est <= UGS_TIER_CAP[0] || bound <= UGS_TIER_CAP[0]) t.first = UGS_TIER_S;
-    else if (est <= UGS_TIER_CAP[1] || bound <= UGS_TIER_CAP[1]) t.first = UGS_TIER_M;
-    else t.first = UGS_TIER_L;
-    if (const char *e = std::getenv("UGS_FORCE_TIER")) { int f = std::atoi(e); if (f >= 0 && f <= 2) t.first = f; }
+    t.first = UGS_TIER_L;
+    for (int tier = UGS_TIER_S; tier < UGS_TIER_L; ++tier)
+        if (est <= UGS_TIER_CAP[tier] || bound <= UGS_TIER_CAP[tier]) { t.first = tier; break; }
+    if (const char *e = std::getenv("UGS_FORCE_TIER")) { int f = std::atoi(e); if (f >= 0 && f < UGS_LDS_TIERS) t.first = f; }
     // A tier hands a walk on when its candidate list would overflow (bound > CAP) OR when its hash-table guard trips:
     // `vertices seen + candidate lanes of the chunk > hash limit`, which is conservative (the lanes need not be new).  A walk
     // has seen at most bound + 1 vertices, so the guard can trip as soon as bound + 1 + lanes-per-walk exceeds the limit --
     // for the 448-candidate tier (limit 448, 64 lanes) already from bound 384.
     auto may_hand_on = [&](int tier) { return bound > UGS_TIER_CAP[tier] || bound + 1 + UGS_TIER_LANES[tier] > UGS_TIER_HASH_LIMIT[tier]; };
-    t.second_L = t.first < UGS_TIER_L && may_hand_on(t.first);
-    t.third_G = may_hand_on(UGS_TIER_L);
+    // handed-on rows are redone ONCE by the smallest LDS tier that cannot hand on itself (else the largest), then by the
+    // global-memory tier if even that one can
+    if (t.first < UGS_TIER_L && may_hand_on(t.first)) {
+        t.second = UGS_TIER_L;
+        for (int tier = t.first + 1; tier < UGS_TIER_L; ++tier) if (!may_hand_on(tier)) { t.second = tier; break; }
+    }
+    const int last_lds = t.second >= 0 ? t.second : t.first;
+    t.third_G = may_hand_on(last_lds);
     p->tiers[k] = t;
     return t;
 }
@@ -950,7 +956,7 @@ int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
     if (int rc = ensure(plan->counts, (size_t)row_count * sizeof(uint32_t), plan->device)) return rc;
     if (int rc = ensure(plan->scantmp, (size_t)ugs_scan_tmp_words(row_count) * sizeof(int64_t), plan->device)) return rc;
     if (int rc = ensure(plan->ovfcnt, 4 * sizeof(uint32_t), plan->device)) return rc;
-    const bool may_overflow = tc.second_L || tc.third_G;
+    const bool may_overflow = tc.second >= 0 || tc.third_G;
     if (may_overflow) {
         if (int rc = ensure(plan->ovf1, (size_t)row_count * sizeof(int64_t), plan->device)) return rc;
         if (int rc = ensure(plan->ovf2, (size_t)row_count * sizeof(int64_t), plan->device)) return rc;
@@ -988,10 +994,10 @@ int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
     HIP_TRY(ev_end(plan, s));
     HIP_TRY(ev_begin(plan, 1, s));
     int last = 0;   // index of the counter holding rows that nobody processed
-    if (tc.second_L) {
+    if (tc.second >= 0) {
         a.in_list = static_cast<const int64_t *>(plan->ovf1.p); a.in_count = cnt + 0;
         a.ovf_list = static_cast<int64_t *>(plan->ovf2.p); a.ovf_count = cnt + 1;
-        HIP_TRY(ugs_launch_walk(a, UGS_TIER_L, plan->cus, s, nullptr));
+        HIP_TRY(ugs_launch_walk(a, tc.second, plan->cus, s, nullptr));
         last = 1;
     }
     if (tc.third_G) {

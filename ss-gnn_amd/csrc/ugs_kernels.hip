@@ -580,7 +580,7 @@ __device__ __forceinline__ uint32_t stage_final(const Work<LdsSpace> &ws, const 
 // waits on them), the elements-per-lane variant of a materialising stage is fixed at compile time, and a final stage only
 // carries the variants its candidate range (B[stage-1], min(B[stage], CAP)] can need.
 constexpr int nj_of(int per) { return per <= 1 ? 1 : per <= 3 ? 3 : per <= 5 ? 5 : per <= 7 ? 7 : per <= 9 ? 9 : per <= 13 ? 13 : per <= 17 ? 17 : 33; }
-constexpr int nst_of(int cap) { return cap <= 64 ? 3 : (cap <= 512 ? 5 : 7); }       // stages that are ever materialised
+constexpr int nst_of(int cap) { return cap <= 64 ? 3 : (cap <= 512 ? 5 : (cap <= 1024 ? 6 : 7)); }       // stages that are ever materialised
 
 template <int STAGE> struct ChainAt {
     static constexpr uint32_t B = kChainHost[STAGE], M = cmagic(kChainHost[STAGE]), S = (uint32_t)clog2(kChainHost[STAGE]) - 1u;
@@ -931,13 +931,13 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
 
 // LDS words of one group's workspace for a tier (all sub-arrays 16-byte aligned)
 template <int CAP> struct TierCfg {
-    static constexpr int NSTAGE = CAP <= 64 ? 3 : (CAP <= 512 ? 5 : 7);           // stages that are ever materialised
-    static constexpr int ORDW = (int)((ord_words_before(NSTAGE) + 3u) & ~3u);     // 104 / 492 / 2144 words
-    static constexpr int BCAP = CAP <= 64 ? 127 : (CAP <= 512 ? 541 : 2357);      // smallest chain value >= CAP
+    static constexpr int NSTAGE = nst_of(CAP);                                     // stages that are ever materialised
+    static constexpr int ORDW = (int)((ord_words_before(NSTAGE) + 3u) & ~3u);     // 104 / 492 / 1036 / 2144 words
+    static constexpr int BCAP = CAP <= 64 ? 127 : (CAP <= 512 ? 541 : (CAP <= 1024 ? 1109 : 2357));   // smallest chain value >= CAP
     static constexpr int BCAP_A = (BCAP + 3) & ~3;
-    static constexpr int HS = CAP <= 64 ? 128 : (CAP <= 512 ? 512 : 4096);
+    static constexpr int HS = CAP <= 64 ? 128 : (CAP <= 512 ? 512 : (CAP <= 1024 ? 2048 : 4096));
     static constexpr int HLIMIT = CAP <= 512 && CAP > 64 ? HS / 8 * 7 : HS / 4 * 3;   // max distinct vertices a walk may have seen
-    static_assert(HLIMIT == UGS_TIER_HASH_LIMIT[CAP <= 64 ? 0 : (CAP <= 512 ? 1 : 2)], "host tier logic (choose_tier) relies on this limit");
+    static_assert(HLIMIT == UGS_TIER_HASH_LIMIT[CAP <= 64 ? 0 : (CAP <= 512 ? 1 : (CAP <= 1024 ? 2 : 3))], "host tier logic (choose_tier) relies on this limit");
     static constexpr int ELW = CAP > 64 ? 4 * UGS_STAGE_ENTRIES : 0;             // staged hits (one-walk-per-wave tiers)
     static constexpr int WORDS = CAP /*D*/ + ORDW + BCAP_A /*TBL*/ + HS /*HK*/ + UGS_KMAX /*SV*/ + ELW;
 };
@@ -949,7 +949,7 @@ template <int CAP> struct TierCfg {
 // CU is throughput-bound (issue + LDS) at ~16 waves, so occupancy is not a lever any more.  The LDS admits 20 one-wave
 // blocks per CU for CAP 448 (5 per SIMD) and 2 four-wave blocks for CAP 64 (2 per SIMD)
 template <int GS, int CAP, int BLOCK>
-__global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 4 : (CAP <= 64 ? 2 : 1)) void ugs_walk_lds(UgsWalkArgs a) {
+__global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 4 : (CAP <= 64 || CAP == 1024 ? 2 : 1)) void ugs_walk_lds(UgsWalkArgs a) {
     using Cfg = TierCfg<CAP>;
     constexpr int GROUPS = BLOCK / GS;
     __shared__ __attribute__((aligned(16))) uint32_t lds[GROUPS * Cfg::WORDS];
@@ -1298,6 +1298,7 @@ hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, hipStream_t 
     case UGS_TIER_S: return launch_lds<8, 64, 256>(a, cus, 2, s, info, "ugs_walk_lds<8,64>");
     // one walk per wave: two walks per wave (GS 32) measured 26.4 ms vs 18.7 ms per 1M walks on C5 (two chunks per row)
     case UGS_TIER_M: return launch_lds<64, 448, 64>(a, cus, 16, s, info, "ugs_walk_lds<64,448>");   // 4 waves/SIMD resident (registers)
+    case UGS_TIER_X: return launch_lds<64, 1024, 64>(a, cus, 7, s, info, "ugs_walk_lds<64,1024>");   // 21.5 KB of LDS per walk: 7 fit
     case UGS_TIER_L: return launch_lds<64, 2048, 64>(a, cus, 3, s, info, "ugs_walk_lds<64,2048>");   // 43 KB of LDS per walk: 3 fit
     default: {
         int64_t grid = a.gws_words_per_group > 0 ? a.gws_groups : 0;

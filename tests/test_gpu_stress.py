@@ -17,10 +17,10 @@ def _case(rng):
     G = rng.randint(1, 4)
     cols, ptr = [], [0]
     for _ in range(G):
-        n = rng.choice([5, 12, 30, 70, 150, 400, 460])
+        n = rng.choice([5, 12, 30, 70, 150, 400, 460, 1100])
         p = rng.choice([0.02, 0.05, 0.15, 0.4, 0.9])
         if n >= 150:
-            p = min(p, 0.4)
+            p = min(p, 0.4 if n < 1000 else 0.15)
         off = ptr[-1]
         e = [(u + off, v + off) for u in range(n) for v in range(u + 1, n) if rng.random() < p]
         if rng.random() < 0.4:
@@ -41,7 +41,7 @@ def _case(rng):
             rng.choice([42, 0, -7, 123456]))
 
 
-@pytest.mark.parametrize("tier", [None, "0", "1", "2"])
+@pytest.mark.parametrize("tier", [None, "0", "1", "2", "3"])
 def test_random_batches_under_every_first_tier(tier, monkeypatch):
     import ugs_sampler
     if tier is None:
