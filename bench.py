@@ -317,6 +317,21 @@ def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
         plan.fill(m, nodes, eptr, None, "sample", 0, out=(eidx, esrc))
     torch.cuda.synchronize()
     dt_dev = (time.perf_counter() - t) / reps
+    # the same step captured once as a HIP graph and replayed (Plan.graph_step)
+    dt_graph = None
+    try:
+        step = plan.graph_step(m, "sample", 0, rows, edge_capacity=cap)
+        for i in range(5):
+            step.launch(42 + i)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for i in range(reps):
+            step.launch(42 + i)
+        torch.cuda.synchronize()
+        dt_graph = (time.perf_counter() - t) / reps
+        step.close()
+    except Exception as e:   # noqa: BLE001
+        print(f"[bench] graph step on {name} failed: {e}", file=sys.stderr)
     for _ in range(3):
         ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode="sample", seed=42)
     t = time.perf_counter()
@@ -342,6 +357,8 @@ def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
     torch.cuda.synchronize()
     dt_devout = (time.perf_counter() - t) / reps
     res = {"rows": rows, "k": k, "device_resident_subgraphs_per_s": round(rows / dt_dev, 1), "device_resident_ms": round(dt_dev * 1e3, 4),
+           "hip_graph_replay_subgraphs_per_s": round(rows / dt_graph, 1) if dt_graph else None,
+           "hip_graph_replay_ms": round(dt_graph * 1e3, 4) if dt_graph else None,
            "drop_in_call_subgraphs_per_s": round(rows / dt_host, 1), "drop_in_call_ms": round(dt_host * 1e3, 4),
            "drop_in_call_shuffled_batch_ms": round(dt_shuf * 1e3, 4), "drop_in_call_device_out_ms": round(dt_devout * 1e3, 4)}
     try:

@@ -119,6 +119,17 @@ int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
 int ugs_plan_fill(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int64_t row_begin,
                   int64_t row_count, void *stream, const int64_t *d_nodes, const int64_t *d_edge_ptr,
                   int64_t *d_edge_index, int64_t ld, int64_t *d_edge_src);
+/* A whole step (seed upload, walk tiers, scan, fill) of a plan captured ONCE as a HIP graph and replayed with a new seed:
+ * for batches of small graphs a step is a handful of launches for tens of microseconds of work, and the graph removes the
+ * per-launch gaps.  The buffers are the caller's (d_edge_index[2, ld], d_edge_src[ld]: ld >= the largest total it expects;
+ * a replay whose total exceeds ld must not be used -- compare d_edge_ptr[row_count] with ld).  No reference counterpart
+ * (the reference launches nothing); same results as ugs_plan_walk + ugs_plan_fill with that seed. */
+typedef struct ugs_graph ugs_graph;
+int ugs_plan_graph_create(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int64_t row_begin,
+                          int64_t row_count, int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *d_edge_index, int64_t ld,
+                          int64_t *d_edge_src, ugs_graph **graph_out);
+int ugs_plan_graph_launch(ugs_graph *graph, int seed, void *stream);
+int ugs_plan_graph_destroy(ugs_graph *graph);
 /* Name and per-launch statistics of the kernels the last ugs_plan_walk / ugs_plan_fill on this plan launched
  * (grid, block, LDS bytes) -- used by bench.py to label its roofline line. */
 int ugs_plan_last_launch(const ugs_plan *plan, char *name_buf, int name_buf_len, int *grid, int *block,

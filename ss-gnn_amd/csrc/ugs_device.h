@@ -57,6 +57,7 @@ struct UgsWalkArgs {
     int32_t pad;
     int64_t extra_node_off;  // handle API "global": base_offset
     uint64_t seed64;         // (uint64_t)(int64_t)seed
+    const uint64_t *seed_ptr;// if not NULL the seed is read from here (captured HIP graphs: the value changes between replays)
     int64_t row_begin;       // first of the G*m rows produced by this call
     int64_t row_count;
     int64_t *nodes;          // [row_count, k]

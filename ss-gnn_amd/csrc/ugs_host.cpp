@@ -941,8 +941,16 @@ int ugs_plan_info(const ugs_plan *plan, int k, int64_t *num_graphs, int64_t *num
     return UGS_OK;
 }
 
+static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int seed, const uint64_t *d_seed_ptr,
+                          int64_t row_begin, int64_t row_count, void *stream, int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *total_edges_host);
+
 int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int seed, int64_t row_begin,
                   int64_t row_count, void *stream, int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *total_edges_host) {
+    return plan_walk_impl(plan, m_per_graph, k, mode, extra_node_offset, seed, nullptr, row_begin, row_count, stream, d_nodes, d_edge_ptr, total_edges_host);
+}
+
+static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int seed, const uint64_t *d_seed_ptr,
+                          int64_t row_begin, int64_t row_count, void *stream, int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *total_edges_host) {
     if (!plan) return fail(UGS_E_BAD_ARG, "plan is null");
     if (k < 1) return fail(UGS_E_BAD_ARG, "k must be >= 1");
     if (k > UGS_KMAX) return fail(UGS_E_UNSUPPORTED, "k > 32 is not supported by the HIP sampler");
@@ -983,6 +991,7 @@ int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
     a.m = m_per_graph; a.k = k; a.mode = mode;
     a.extra_node_off = extra_node_offset;
     a.seed64 = (uint64_t)(int64_t)seed;
+    a.seed_ptr = d_seed_ptr;
     a.row_begin = row_begin; a.row_count = row_count;
     a.nodes = d_nodes;
     a.counts = static_cast<uint32_t *>(plan->counts.p);
@@ -1074,6 +1083,95 @@ int ugs_plan_fill(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
     HIP_TRY(ev_begin(plan, 2, static_cast<hipStream_t>(stream)));
     HIP_TRY(ugs_launch_fill(a, tc.first != UGS_TIER_S, plan->cus, static_cast<hipStream_t>(stream), &plan->last_fill));
     HIP_TRY(ev_end(plan, static_cast<hipStream_t>(stream)));
+    return UGS_OK;
+}
+
+// ---- a step captured as a HIP graph (include/ugs_mi355.h) -----------------------------------------------------------------
+struct ugs_graph {
+    ugs_plan *owner = nullptr;       // keeps the device arrays alive
+    ugs_plan *shadow = nullptr;      // the same device arrays with PRIVATE scratch: the graph bakes scratch pointers in, and the
+                                     // owner's scratch may be regrown by later calls
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipGraphNode_t seed_node = nullptr;
+    hipStream_t cs = nullptr;
+    uint64_t *h_seeds = nullptr;     // pinned ring: a replay's seed must stay put until its upload node has run
+    uint64_t *d_seed = nullptr;
+    int slot = 0, device = -1;
+};
+static const int kSeedRing = 256;
+
+int ugs_plan_graph_destroy(ugs_graph *g) {
+    if (!g) return UGS_OK;
+    if (g->device >= 0 && hipSetDevice(g->device) == hipSuccess) (void)hipDeviceSynchronize();
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    if (g->cs) (void)hipStreamDestroy(g->cs);
+    if (g->h_seeds) (void)hipHostFree(g->h_seeds);
+    if (g->d_seed) (void)hipFree(g->d_seed);
+    if (g->shadow) plan_unref(g->shadow);
+    if (g->owner) plan_unref(g->owner);
+    delete g;
+    return UGS_OK;
+}
+
+int ugs_plan_graph_create(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int64_t row_begin, int64_t row_count,
+                          int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *d_edge_index, int64_t ld, int64_t *d_edge_src, ugs_graph **graph_out) {
+    if (!plan || !graph_out) return fail(UGS_E_BAD_ARG, "null argument");
+    if (row_count <= 0 || !d_nodes || !d_edge_ptr || !d_edge_index || !d_edge_src || ld <= 0) return fail(UGS_E_BAD_ARG, "a captured step needs rows and all four output buffers");
+    HIP_TRY(hipSetDevice(plan->device));
+    auto *g = new ugs_graph();
+    g->device = plan->device;
+    plan->refs.fetch_add(1);
+    g->owner = plan;
+    auto *sh = new ugs_plan();
+    sh->device = plan->device; sh->cus = plan->cus; sh->G = plan->G; sh->nverts = plan->nverts; sh->nnz = plan->nnz;
+    sh->dev = plan->dev;             // device arrays shared, not owned (blob stays null)
+    sh->g_n = plan->g_n; sh->g_maxdeg = plan->g_maxdeg; sh->g_sbdeg = plan->g_sbdeg; sh->g_level = plan->g_level;
+    g->shadow = sh;
+    auto bail = [&](int rc) { ugs_plan_graph_destroy(g); return rc; };
+    hipError_t e = hipStreamCreateWithFlags(&g->cs, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&g->h_seeds), kSeedRing * sizeof(uint64_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&g->d_seed), sizeof(uint64_t));
+    if (e != hipSuccess) return bail(fail_hip(e, "graph resources"));
+    g->h_seeds[0] = 0;
+    // 1. an ordinary step: every scratch buffer of the shadow plan gets its final size before anything is captured
+    if (int rc = plan_walk_impl(sh, m_per_graph, k, mode, extra_node_offset, 0, nullptr, row_begin, row_count, g->cs, d_nodes, d_edge_ptr, nullptr)) return bail(rc);
+    if (int rc = ugs_plan_fill(sh, m_per_graph, k, mode, extra_node_offset, row_begin, row_count, g->cs, d_nodes, d_edge_ptr, d_edge_index, ld, d_edge_src)) return bail(rc);
+    e = hipStreamSynchronize(g->cs);
+    if (e != hipSuccess) return bail(fail_hip(e, "graph warm-up"));
+    // 2. the same step captured, reading its seed from d_seed
+    e = hipStreamBeginCapture(g->cs, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) return bail(fail_hip(e, "hipStreamBeginCapture"));
+    int rc = plan_walk_impl(sh, m_per_graph, k, mode, extra_node_offset, 0, g->d_seed, row_begin, row_count, g->cs, d_nodes, d_edge_ptr, nullptr);
+    if (!rc) rc = ugs_plan_fill(sh, m_per_graph, k, mode, extra_node_offset, row_begin, row_count, g->cs, d_nodes, d_edge_ptr, d_edge_index, ld, d_edge_src);
+    e = hipStreamEndCapture(g->cs, &g->graph);
+    if (rc) return bail(rc);
+    if (e != hipSuccess || !g->graph) return bail(fail_hip(e, "hipStreamEndCapture"));
+    // 3. the seed upload as an explicit root node every captured root depends on (its source slot is re-pointed per replay)
+    size_t nroots = 0;
+    e = hipGraphGetRootNodes(g->graph, nullptr, &nroots);
+    std::vector<hipGraphNode_t> roots(nroots);
+    if (e == hipSuccess && nroots) e = hipGraphGetRootNodes(g->graph, roots.data(), &nroots);
+    const bool static_seed = std::getenv("UGS_GRAPH_STATIC") != nullptr;   // measurement aid: replay without the seed upload
+    if (e == hipSuccess && !static_seed) e = hipGraphAddMemcpyNode1D(&g->seed_node, g->graph, nullptr, 0, g->d_seed, g->h_seeds, sizeof(uint64_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && nroots && !static_seed) {
+        std::vector<hipGraphNode_t> from(nroots, g->seed_node);
+        e = hipGraphAddDependencies(g->graph, from.data(), roots.data(), nroots);
+    }
+    if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) return bail(fail_hip(e, "building the graph"));
+    *graph_out = g;
+    return UGS_OK;
+}
+
+int ugs_plan_graph_launch(ugs_graph *g, int seed, void *stream) {
+    if (!g || !g->exec) return fail(UGS_E_BAD_ARG, "graph is null");
+    HIP_TRY(hipSetDevice(g->device));
+    g->slot = (g->slot + 1) % kSeedRing;
+    g->h_seeds[g->slot] = (uint64_t)(int64_t)seed;
+    if (g->seed_node) HIP_TRY(hipGraphExecMemcpyNodeSetParams1D(g->exec, g->seed_node, g->d_seed, g->h_seeds + g->slot, sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream)));
     return UGS_OK;
 }
 

@@ -836,7 +836,7 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
     STAMP_DECL;
     STAMP_BEGIN();
     Rng rng;
-    rng.init(a.seed64 + (uint64_t)i * 0x9e3779b97f4a7c15ull);
+    rng.init((a.seed_ptr ? *a.seed_ptr : a.seed64) + (uint64_t)i * 0x9e3779b97f4a7c15ull);
     uint32_t root_vi, root_v;
     if (gd.level == 0) {      // alias draw: two numbers (reference include/sampler.hpp:72-77)
         uint32_t j = (uint32_t)(rng.next() % (uint64_t)(uint32_t)gd.n);

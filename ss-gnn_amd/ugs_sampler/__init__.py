@@ -187,6 +187,48 @@ def sample_batch(edge_index, ptr, m_per_graph, k, mode="sample", seed=42, *, dev
     return nodes, edge_index_t, edge_ptr, sample_ptr, edge_src
 
 
+class GraphStep:
+    """Plan.graph_step(): nodes [rows,k], edge_ptr [rows+1], edge_index [2,capacity], edge_src [capacity] live on the device and
+    are overwritten by every launch(seed); `result()` trims the edge arrays to the step's total (one host sync)."""
+
+    def __init__(self, plan, m, mode, row_begin, row_count, edge_capacity):
+        dev = torch.device("cuda", torch.cuda.current_device())
+        k = plan.k
+        if edge_capacity is None:
+            edge_capacity = max(1, row_count * k * (k - 1))          # every ordered pair of every row (simple graphs)
+        self.plan, self.rows, self.capacity = plan, row_count, int(edge_capacity)
+        self.nodes = torch.empty((row_count, k), dtype=torch.int64, device=dev)
+        self.edge_ptr = torch.empty((row_count + 1,), dtype=torch.int64, device=dev)
+        self.edge_index = torch.empty((2, self.capacity), dtype=torch.int64, device=dev)
+        self.edge_src = torch.empty((self.capacity,), dtype=torch.int64, device=dev)
+        h = vp()
+        code = _BATCH_MODES[mode] if mode in _BATCH_MODES else _EDGE_MODES[mode]
+        check(lib.ugs_plan_graph_create(plan._h, m, k, code, 0, row_begin, row_count, self.nodes.data_ptr(), self.edge_ptr.data_ptr(),
+                                        self.edge_index.data_ptr(), self.capacity, self.edge_src.data_ptr(), C.byref(h)))
+        self._h = h
+
+    def launch(self, seed):
+        check(lib.ugs_plan_graph_launch(self._h, _as_c_int(seed, "seed"), torch.cuda.current_stream().cuda_stream))
+        return self
+
+    def result(self):
+        total = int(self.edge_ptr[-1].item())
+        if total > self.capacity:
+            raise RuntimeError(f"edge capacity {self.capacity} too small for {total} edge entries")
+        return self.nodes, self.edge_index[:, :total], self.edge_ptr, self.edge_src[:total]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.ugs_plan_graph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def clear_cache():
     """Drop the preprocessing LRU and the cached device plans (what a fresh process has)."""
     check(lib.ugs_cache_clear())
@@ -292,6 +334,14 @@ class Plan:
                                 edge_ptr.data_ptr(), edge_index.data_ptr(), edge_index.stride(0) if edge_index.size(1) else 0,
                                 edge_src.data_ptr()))
         return edge_index, edge_src
+
+    def graph_step(self, m_per_graph, mode="sample", row_begin=0, row_count=None, edge_capacity=None):
+        """The whole step (walk tiers, scan, fill) for a fixed row range captured once as a HIP graph; `launch(seed)` replays it
+        on the current stream into the step's own device tensors.  For launch-bound batches of small graphs."""
+        m = _as_c_int(m_per_graph, "m_per_graph")
+        if row_count is None:
+            row_count = self.num_graphs * m - row_begin
+        return GraphStep(self, m, mode, int(row_begin), int(row_count), edge_capacity)
 
     def sample_rows(self, m_per_graph, mode="sample", seed=42, row_begin=0, row_count=None):
         """(nodes, edge_index, edge_ptr, edge_src) for rows [row_begin, row_begin+row_count) as device tensors."""

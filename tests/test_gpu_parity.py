@@ -386,3 +386,32 @@ def test_fill_after_another_walk_reads_the_rows_again(monkeypatch):
     assert torch.equal(e2.cpu(), want_b[1][:, lo:hi]) and torch.equal(s2.cpu(), want_b[4][lo:hi])
     plan.close()
     ugs_sampler.clear_cache()
+
+
+def test_step_captured_as_hip_graph_equals_the_launched_step(monkeypatch):
+    """Plan.graph_step: walk tiers + scan + fill captured once and replayed with new seeds give exactly what the separately
+    launched step gives -- TU-shaped batch (8-lane tier, row-reading fill) and an ER graph (64-lane tier, staged fill),
+    every mode, a row sub-range; a later, larger ordinary call on the same plan must not disturb the captured scratch."""
+    import torch
+    import ugs_sampler
+    import ugs_workloads as wl
+    ugs_sampler.clear_cache()
+    ei, ptr = wl.tu_batch(39, 73, 8)
+    er, erptr = wl.er_graph(3000, 60000, seed=2)
+    for (e, p, m, k) in ((ei, ptr, 64, 6), (er, erptr, 500, 6)):
+        e_t, p_t = torch.from_numpy(e), torch.from_numpy(p)
+        plan = ugs_sampler.Plan.from_batch(e_t, p_t, k)
+        rows = (len(p) - 1) * m
+        for mode in ("sample", "graph", "global"):
+            for (rb, rc) in ((0, rows), (7, rows // 2)):
+                step = plan.graph_step(m, mode, row_begin=rb, row_count=rc)
+                for seed in (42, 0, -5, 99):
+                    got = step.launch(seed).result()
+                    want = plan.sample_rows(m, mode=mode, seed=seed, row_begin=rb, row_count=rc)
+                    for g, w in zip(got, want):
+                        assert torch.equal(g, w), (mode, rb, rc, seed)
+                    if seed == 0:
+                        plan.sample_rows(2 * m, mode=mode, seed=1)           # regrows the plan's own scratch
+                step.close()
+        plan.close()
+    ugs_sampler.clear_cache()
