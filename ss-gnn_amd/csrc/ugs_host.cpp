@@ -976,7 +976,7 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
         if (int rc = ensure(plan->ovf2, (size_t)row_count * sizeof(int64_t), plan->device)) return rc;
     }
     // edge staging by the walk (tiers with one walk per wave): 512 bytes of scratch per row, bounded
-    static const int64_t stage_max = [] { const char *e = std::getenv("UGS_STAGE_MAX_MB"); return (e ? std::atoll(e) : 4096) << 20; }();
+    const int64_t stage_max = [] { const char *e = std::getenv("UGS_STAGE_MAX_MB"); return (int64_t)(e ? std::atoll(e) : 4096) << 20; }();   // read per call (tests toggle it)
     const bool stg = tc.first != UGS_TIER_S && row_count * (int64_t)(UGS_STAGE_ITEMS * sizeof(uint2)) <= stage_max;
     plan->stg_valid = false;
     if (stg) {

@@ -415,3 +415,17 @@ def test_step_captured_as_hip_graph_equals_the_launched_step(monkeypatch):
                 step.close()
         plan.close()
     ugs_sampler.clear_cache()
+
+
+def test_staging_switched_off_by_its_memory_bound(product, orc, monkeypatch):
+    """UGS_STAGE_MAX_MB bounds the staging scratch (512 B per row); a call above the bound takes the row-reading fill kernel
+    for every row of the 64-lane tiers -- same output."""
+    monkeypatch.setenv("UGS_FORCE_TIER", "1")
+    monkeypatch.setenv("UGS_STAGE_MAX_MB", "0")
+    rng = random.Random(77)
+    n = 90
+    e = [(u, v) for u in range(n) for v in range(u + 1, n) if rng.random() < 0.15]
+    ei = np.array(e + [(v, u) for u, v in e[:40]], dtype=np.int64).T.reshape(2, -1).copy()
+    calls = [dict(fn="sample_batch", edge_index=ei, ptr=np.array([0, n], dtype=np.int64), m=300, k=7, mode=mode, seed=3)
+             for mode in ("sample", "graph", "global")]
+    _same(calls, product, orc, "staging off")
