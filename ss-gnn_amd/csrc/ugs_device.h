@@ -79,6 +79,10 @@ struct UgsWalkArgs {
     // when it scans the row of the later endpoint, so complete rows leave their directed edge items here in OUTPUT order
     // and the fill kernel only expands them.  Rows that do not fit (or ran in a tier without staging) are flagged 0 and,
     // if they have edges, listed for the row-reading fill kernel.
+    // dynamic work distribution: the first gridsize*groups items are taken statically, every further item index is
+    // groups_total + atomicAdd(work_next, 1) (NULL: static striding).  A walk's cost varies (degrees, which stages of the order
+    // get invalidated), so a static split ends with the unluckiest wave.
+    unsigned long long *work_next;
     uint2 *stage;            // [row_count, UGS_STAGE_ITEMS]: x = batch column, y = source local index | target local index << 8
     uint8_t *staged;         // [row_count] 1 = row's items are in `stage`
     int64_t *ulist;          // rows (relative) with edges that are NOT staged

@@ -428,7 +428,7 @@ struct ugs_plan {
     PoolBuf counts, ovf1, ovf2, ovfcnt, scantmp, gws;
     // edges staged by the last walk (UgsWalkArgs::stage) and the call they belong to: a fill of exactly those rows into/from
     // the same nodes buffer expands them; any other fill reads the adjacency rows again
-    PoolBuf stage, staged, ulist;
+    PoolBuf stage, staged, ulist, work;   // work: 3 x u64 next-item counters (one per walk launch of a call)
     bool stg_valid = false;
     const void *stg_nodes = nullptr;
     int64_t stg_row_begin = 0, stg_row_count = 0;
@@ -622,7 +622,7 @@ void destroy_plan(ugs_plan *p) {
     ev_clear(p);
     if (p->blob_buf.p) pool_put(p->blob_buf); else if (p->blob) (void)hipFree(p->blob);
     pool_put(p->counts); pool_put(p->ovf1); pool_put(p->ovf2); pool_put(p->ovfcnt); pool_put(p->scantmp);
-    pool_put(p->stage); pool_put(p->staged); pool_put(p->ulist);
+    pool_put(p->stage); pool_put(p->staged); pool_put(p->ulist); pool_put(p->work);
     if (p->gws.p) { (void)hipFree(p->gws.p); p->gws = PoolBuf(); }
     delete p;
 }
@@ -985,6 +985,12 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
         if (int rc = ensure(plan->ulist, (size_t)row_count * sizeof(int64_t), plan->device)) return rc;
     }
     if (may_overflow || stg) HIP_TRY(hipMemsetAsync(plan->ovfcnt.p, 0, 4 * sizeof(uint32_t), s));   // nothing else reads the counters
+    // dynamic work distribution pays when a launch has many more walks than resident groups (its counter costs one memset)
+    const bool dyn = tc.first != UGS_TIER_S && row_count > (int64_t)plan->cus * 64 && std::getenv("UGS_STATIC_SPLIT") == nullptr;
+    if (dyn) {
+        if (int rc = ensure(plan->work, 4 * sizeof(unsigned long long), plan->device)) return rc;
+        HIP_TRY(hipMemsetAsync(plan->work.p, 0, 4 * sizeof(unsigned long long), s));
+    }
     uint32_t *cnt = static_cast<uint32_t *>(plan->ovfcnt.p);
     UgsWalkArgs a{};
     a.plan = plan->dev;
@@ -1004,6 +1010,7 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
         plan->stg_valid = true; plan->stg_nodes = d_nodes; plan->stg_row_begin = row_begin; plan->stg_row_count = row_count;
         plan->stg_m = m_per_graph; plan->stg_k = k;
     }
+    a.work_next = dyn ? static_cast<unsigned long long *>(plan->work.p) + 0 : nullptr;
     HIP_TRY(ev_begin(plan, 0, s));
     HIP_TRY(ugs_launch_walk(a, tc.first, plan->cus, s, &plan->last_walk));
     HIP_TRY(ev_end(plan, s));
@@ -1012,6 +1019,7 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
     if (tc.second >= 0) {
         a.in_list = static_cast<const int64_t *>(plan->ovf1.p); a.in_count = cnt + 0;
         a.ovf_list = static_cast<int64_t *>(plan->ovf2.p); a.ovf_count = cnt + 1;
+        a.work_next = dyn ? static_cast<unsigned long long *>(plan->work.p) + 1 : nullptr;
         HIP_TRY(ugs_launch_walk(a, tc.second, plan->cus, s, nullptr));
         last = 1;
     }
@@ -1038,6 +1046,7 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
         a.gws = static_cast<uint32_t *>(plan->gws.p);
         a.gws_words_per_group = plan->gws_words; a.gws_groups = plan->gws_groups;
         a.gcap = plan->gcap; a.ghs = plan->ghs; a.gbcap = plan->gbcap; a.gpcap = plan->gpcap;
+        a.work_next = nullptr;              // the global tier keeps one walk per workspace slice, static
         HIP_TRY(ugs_launch_walk(a, UGS_TIER_G, plan->cus, s, nullptr));
         last = 2;
     }

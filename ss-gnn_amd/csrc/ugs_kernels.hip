@@ -989,6 +989,29 @@ __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 4 : (CAP <= 64 ||
     ws.hlimit = Cfg::HLIMIT;
     const int64_t total = a.in_list ? (int64_t)*a.in_count : a.row_count;
     const int64_t ngroups = (int64_t)gridDim.x * GROUPS;
+    if (a.work_next) {
+        // dynamic split in chunks of kWorkChunk consecutive items: one counter round trip per chunk (a single hot address
+        // answers in several microseconds), balance to within a chunk at the end of the launch
+#ifndef UGS_WORK_CHUNK
+#define UGS_WORK_CHUNK 4
+#endif
+        constexpr int64_t kWorkChunk = UGS_WORK_CHUNK;
+        int64_t it = ((int64_t)blockIdx.x * GROUPS + gib) * kWorkChunk;
+        while (it < total) {
+            const int64_t end = it + kWorkChunk < total ? it + kWorkChunk : total;
+            for (; it < end; ++it) {
+                const int64_t row_rel = a.in_list ? a.in_list[it] : it;
+                if (!do_walk<GS, LdsSpace, (CAP + GS - 1) / GS>(ws, g, a, row_rel, SV, EL)) {
+                    if (g.lane == 0 && a.ovf_list) { uint32_t pos = atomicAdd(a.ovf_count, 1u); a.ovf_list[pos] = row_rel; }
+                }
+            }
+            unsigned long long nxt = 0ull;
+            if (g.lane == 0) nxt = atomicAdd(a.work_next, 1ull);
+            const uint32_t lo = g.bcast((uint32_t)nxt, 0), hi = g.bcast((uint32_t)(nxt >> 32), 0);
+            it = (ngroups + (int64_t)(((unsigned long long)hi << 32) | lo)) * kWorkChunk;
+        }
+        return;
+    }
     for (int64_t it = (int64_t)blockIdx.x * GROUPS + gib; it < total; it += ngroups) {
         const int64_t row_rel = a.in_list ? a.in_list[it] : it;
         if (!do_walk<GS, LdsSpace, (CAP + GS - 1) / GS>(ws, g, a, row_rel, SV, EL)) {
