@@ -986,7 +986,7 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
     }
     if (may_overflow || stg) HIP_TRY(hipMemsetAsync(plan->ovfcnt.p, 0, 4 * sizeof(uint32_t), s));   // nothing else reads the counters
     // dynamic work distribution pays when a launch has many more walks than resident groups (its counter costs one memset)
-    const bool dyn = tc.first != UGS_TIER_S && row_count > (int64_t)plan->cus * 64 && std::getenv("UGS_STATIC_SPLIT") == nullptr;
+    const bool dyn = row_count > (int64_t)plan->cus * (tc.first == UGS_TIER_S ? 1024 : 64) && std::getenv("UGS_STATIC_SPLIT") == nullptr;
     if (dyn) {
         if (int rc = ensure(plan->work, 4 * sizeof(unsigned long long), plan->device)) return rc;
         HIP_TRY(hipMemsetAsync(plan->work.p, 0, 4 * sizeof(unsigned long long), s));
