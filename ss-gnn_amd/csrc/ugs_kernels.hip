@@ -961,14 +961,13 @@ template <int CAP> struct TierCfg {
     static constexpr int WORDS = CAP /*D*/ + ORDW + BCAP_A /*TBL*/ + HS /*HK*/ + UGS_KMAX /*SV*/ + ELW;
 };
 
-// second launch-bounds argument = waves per SIMD the register allocation must allow.  CAP 448: 4 (<= 128 VGPRs, no spills).
-// Measured on C5 (same-box A/B, census build for residency): the LDS is granted in 1280-byte granules, so 8112 B/walk
-// admits 18 one-wave blocks per CU; a grid larger than the resident set runs in two uneven rounds (20/CU: +25 % time);
-// 3 waves/SIMD: 16.9 ms, 4: 13.6 ms; a leaner build (73 VGPRs, CAP 320, 20 resident waves/CU) is SLOWER (14.3 ms): the
-// CU is throughput-bound (issue + LDS) at ~16 waves, so occupancy is not a lever any more.  The LDS admits 20 one-wave
-// blocks per CU for CAP 448 (5 per SIMD) and 2 four-wave blocks for CAP 64 (2 per SIMD)
+// second launch-bounds argument = waves per SIMD the register allocation must allow.  CAP 448: 5 (96 VGPRs, 3 spilled).
+// Measured on C5 (same-box A/B, census build for residency): the LDS is granted in 1280-byte granules, so 8.6 KB/walk
+// admits 18 one-wave blocks per CU (5,5,4,4 per SIMD).  With a STATIC split of the rows 18 blocks/CU was slower than 16
+// (10.63 vs 10.43 ms: a launch ended with the waves of the fuller SIMDs); with the shared work counter the extra waves are
+// pure throughput: 8.81 -> 8.51 ms.  Spilling further to reach more waves costs more than it brings (30 % in an early build).
 template <int GS, int CAP, int BLOCK>
-__global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 4 : (CAP <= 64 || CAP == 1024 ? 2 : 1)) void ugs_walk_lds(UgsWalkArgs a) {
+__global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP <= 64 || CAP == 1024 ? 2 : 1)) void ugs_walk_lds(UgsWalkArgs a) {
     using Cfg = TierCfg<CAP>;
     constexpr int GROUPS = BLOCK / GS;
     __shared__ __attribute__((aligned(16))) uint32_t lds[GROUPS * Cfg::WORDS];
@@ -1339,7 +1338,7 @@ hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, hipStream_t 
     switch (tier) {
     case UGS_TIER_S: return launch_lds<8, 64, 256>(a, cus, 2, s, info, "ugs_walk_lds<8,64>");
     // one walk per wave: two walks per wave (GS 32) measured 26.4 ms vs 18.7 ms per 1M walks on C5 (two chunks per row)
-    case UGS_TIER_M: return launch_lds<64, 448, 64>(a, cus, 16, s, info, "ugs_walk_lds<64,448>");   // 4 waves/SIMD resident (registers)
+    case UGS_TIER_M: return launch_lds<64, 448, 64>(a, cus, 18, s, info, "ugs_walk_lds<64,448>");   // all the LDS admits
     case UGS_TIER_X: return launch_lds<64, 1024, 64>(a, cus, 7, s, info, "ugs_walk_lds<64,1024>");   // 21.5 KB of LDS per walk: 7 fit
     case UGS_TIER_L: return launch_lds<64, 2048, 64>(a, cus, 3, s, info, "ugs_walk_lds<64,2048>");   // 43 KB of LDS per walk: 3 fit
     default: {
