@@ -429,3 +429,25 @@ def test_staging_switched_off_by_its_memory_bound(product, orc, monkeypatch):
     calls = [dict(fn="sample_batch", edge_index=ei, ptr=np.array([0, n], dtype=np.int64), m=300, k=7, mode=mode, seed=3)
              for mode in ("sample", "graph", "global")]
     _same(calls, product, orc, "staging off")
+
+
+@pytest.mark.parametrize("tier", [None, "1", "2"])
+def test_large_launches_share_work_through_a_counter(tier, product, orc, monkeypatch):
+    """Launches with many more walks than resident groups hand the walks out dynamically (chunks of 4 rows per atomicAdd);
+    which wave samples a row must not matter: same rows as the oracle, and as the static split (UGS_STATIC_SPLIT)."""
+    import torch
+    import ugs_sampler
+    import ugs_workloads as wl
+    if tier is None:
+        monkeypatch.delenv("UGS_FORCE_TIER", raising=False)
+    else:
+        monkeypatch.setenv("UGS_FORCE_TIER", tier)
+    ei, ptr = wl.tu_batch(39, 73, 8)
+    m = 40000 if tier is None else 6000                  # 320 000 rows in the 8-lane tier, 48 000 in a 64-lane tier
+    calls = [dict(fn="sample_batch", edge_index=ei, ptr=ptr, m=m, k=4, mode="sample", seed=17)]
+    _same(calls, product, orc, f"dynamic split, tier {tier}")
+    dyn = ugs_sampler.sample_batch(torch.from_numpy(ei), torch.from_numpy(ptr), m, 4, "sample", 18)
+    monkeypatch.setenv("UGS_STATIC_SPLIT", "1")
+    sta = ugs_sampler.sample_batch(torch.from_numpy(ei), torch.from_numpy(ptr), m, 4, "sample", 18)
+    for a, b in zip(dyn, sta):
+        assert torch.equal(a, b)
