@@ -451,3 +451,28 @@ def test_large_launches_share_work_through_a_counter(tier, product, orc, monkeyp
     sta = ugs_sampler.sample_batch(torch.from_numpy(ei), torch.from_numpy(ptr), m, 4, "sample", 18)
     for a, b in zip(dyn, sta):
         assert torch.equal(a, b)
+
+
+def test_dynamic_split_with_rows_handed_on_to_the_next_tier():
+    """ER degree 40, k = 12: the 448-candidate tier starts, a few per cent of the walks outgrow it and are redone by the
+    1024-candidate tier from its overflow list -- both launches large enough to use the shared work counter."""
+    import torch
+    import ugs_sampler
+    import oracle
+    import ugs_workloads as wl
+    os.environ.pop("UGS_FORCE_TIER", None)
+    n, k, m = 60000, 12, 40000
+    ei, ptr = wl.er_graph(n, 1_200_000, seed=11)
+    ugs_sampler.clear_cache()
+    plan = ugs_sampler.Plan.from_batch(torch.from_numpy(ei), torch.from_numpy(ptr), k)
+    nodes, eptr, total = plan.walk(m, "sample", 5)
+    handed_on = plan.last_launch()["overflow_rows"]
+    eidx, esrc = plan.fill(m, nodes, eptr, total, "sample")
+    assert plan.info()["tier"] == 1 and handed_on > 0, (plan.info(), handed_on)
+    P = oracle.Preproc(ei, n, k)
+    want = P.sample(m, k, "local", 0, 5)
+    for g, w in zip((nodes, eidx, eptr, esrc), want):
+        assert np.array_equal(g.cpu().numpy(), np.asarray(w))
+    P.close()
+    plan.close()
+    ugs_sampler.clear_cache()
