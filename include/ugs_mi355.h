@@ -123,7 +123,9 @@ int ugs_plan_fill(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
  * for batches of small graphs a step is a handful of launches for tens of microseconds of work, and the graph removes the
  * per-launch gaps.  The buffers are the caller's (d_edge_index[2, ld], d_edge_src[ld]: ld >= the largest total it expects;
  * a replay whose total exceeds ld must not be used -- compare d_edge_ptr[row_count] with ld).  No reference counterpart
- * (the reference launches nothing); same results as ugs_plan_walk + ugs_plan_fill with that seed. */
+ * (the reference launches nothing); same results as ugs_plan_walk + ugs_plan_fill with that seed.  Launches of one graph
+ * must be issued by one thread at a time and on one stream at a time (the outputs are the graph's buffers); up to 256 replays
+ * may be in flight (ring of pinned seed slots). */
 typedef struct ugs_graph ugs_graph;
 int ugs_plan_graph_create(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int64_t row_begin,
                           int64_t row_count, int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *d_edge_index, int64_t ld,
