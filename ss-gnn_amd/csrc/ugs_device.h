@@ -14,6 +14,12 @@
 //   roots   UgsRootRec[sum(n_g)]     alias table row + both candidate root vertices in ONE 24-byte record, so the
 //                                    root draw (reference include/sampler.hpp:72-77 + src/sampler.cpp:165-173) is one gather
 //   viable  int2[...]                (vi, order[vi]) lists for relaxation levels 1/2 (reference src/sampler.cpp:121-150)
+//   prow    int2[sum(n_g) << s]      PADDED ROWS for the one-walk-per-wave tiers (built on the device at the first such walk):
+//                                    vertex v of graph g owns the 2^s entries at (vbase_g + v) << s -- entry 0 is the row's header
+//                                    (CSR degree, absolute CSR position of the row's first entry), entries 1.. are the first
+//                                    2^s - 1 (w, rank(w)) pairs of the row; longer rows continue in adj[].  A walk step then needs
+//                                    ONE dependent memory round trip (the row, at an address computed from the vertex) instead
+//                                    of two (row pointer, then row), and no line is fetched for a row-pointer pair.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -47,6 +53,9 @@ struct UgsPlanDev {
     const UgsRootRec *roots;
     const int2 *viable;
     int64_t num_graphs;
+    const int2 *prow;        // padded rows (NULL until built; the 8-lane and global-memory tiers use rowptr + adj)
+    int32_t prow_shift;      // log2(entries per padded row), 3..6
+    int32_t prow_pad;
 };
 
 struct UgsWalkArgs {
@@ -121,6 +130,7 @@ static constexpr int UGS_TIER_LANES[UGS_LDS_TIERS] = {8, 64, 64, 64};           
 static constexpr int UGS_TIER_HASH_LIMIT[UGS_LDS_TIERS] = {96, 448, 1536, 3072};  // TierCfg<CAP>::HLIMIT (static_assert in ugs_kernels.hip)
 
 hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int device_cus, hipStream_t s, UgsLaunchInfo *info);
+hipError_t ugs_launch_build_prow(const UgsPlanDev &plan, int64_t num_vertices, int2 *prow, int shift, int device_cus, hipStream_t s);
 hipError_t ugs_launch_scan(const uint32_t *counts, int64_t rows, int64_t *edge_ptr, int64_t *block_tmp, hipStream_t s);
 hipError_t ugs_launch_fill(const UgsFillArgs &a, int wide, int device_cus, hipStream_t s, UgsLaunchInfo *info);
 int64_t ugs_scan_tmp_words(int64_t rows);

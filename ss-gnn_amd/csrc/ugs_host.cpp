@@ -429,6 +429,8 @@ struct ugs_plan {
     // edges staged by the last walk (UgsWalkArgs::stage) and the call they belong to: a fill of exactly those rows into/from
     // the same nodes buffer expands them; any other fill reads the adjacency rows again
     PoolBuf stage, staged, ulist, work;   // work: 3 x u64 next-item counters (one per walk launch of a call)
+    PoolBuf prow;                         // padded rows (ugs_device.h), built on the device by the first walk in a one-walk-per-wave tier
+    bool prow_pooled = false, prow_failed = false;
     bool stg_valid = false;
     const void *stg_nodes = nullptr;
     int64_t stg_row_begin = 0, stg_row_count = 0;
@@ -623,6 +625,7 @@ void destroy_plan(ugs_plan *p) {
     if (p->blob_buf.p) pool_put(p->blob_buf); else if (p->blob) (void)hipFree(p->blob);
     pool_put(p->counts); pool_put(p->ovf1); pool_put(p->ovf2); pool_put(p->ovfcnt); pool_put(p->scantmp);
     pool_put(p->stage); pool_put(p->staged); pool_put(p->ulist); pool_put(p->work);
+    if (p->prow.p) { if (p->prow_pooled) pool_put(p->prow); else (void)hipFree(p->prow.p); p->prow = PoolBuf(); }
     if (p->gws.p) { (void)hipFree(p->gws.p); p->gws = PoolBuf(); }
     delete p;
 }
@@ -655,11 +658,11 @@ void plan_cache_put(ugs_plan *p) {
         p->cached = true;
         g_plan_cache.push_front(p);
         size_t bytes = 0;
-        for (auto *q : g_plan_cache) bytes += q->blob_bytes;
+        for (auto *q : g_plan_cache) bytes += q->blob_bytes + q->prow.bytes;
         while (g_plan_cache.size() > g_plan_cache_cap || (bytes > g_plan_cache_bytes_cap && g_plan_cache.size() > 1)) {
             ugs_plan *v = g_plan_cache.back();
             g_plan_cache.pop_back();
-            bytes -= v->blob_bytes;
+            bytes -= v->blob_bytes + v->prow.bytes;
             victims.push_back(v);
         }
     }
@@ -742,6 +745,35 @@ void assign_columns(const int64_t *src, const int64_t *dst, int64_t E, const int
             cstart[(size_t)g + 1] = (int64_t)cols_of.size();
         }
     }
+}
+
+// Padded rows for the one-walk-per-wave tiers (ugs_device.h): 2^shift entries per vertex, sized so that the rows a walk visits
+// (degree ~ the size-biased mean) fit their block with three standard deviations to spare; longer rows continue in adj[].
+// Built by a kernel from the plan's own CSR, once.  UGS_NO_PROW=1 keeps the row-pointer path (A/B measurements, tests of both).
+// Call with plan->mu held.  Failure to allocate is not an error: the walk then reads rows through the row pointer.
+int ensure_prow(ugs_plan *plan, hipStream_t s) {
+    if (plan->dev.prow || plan->prow_failed || plan->nverts <= 0) return UGS_OK;
+    if (const char *e = std::getenv("UGS_NO_PROW")) if (e[0] == '1') return UGS_OK;
+    double sb = 0;
+    for (double x : plan->g_sbdeg) sb = std::max(sb, x);
+    int shift = 3;
+    while (shift < 6 && (double)((1 << shift) - 1) < sb + 3.0 * std::sqrt(sb) + 1.0) ++shift;
+    if (const char *e = std::getenv("UGS_PROW_SHIFT")) { const int f = std::atoi(e); if (f >= 3 && f <= 6) shift = f; }
+    const size_t bytes = ((size_t)plan->nverts << shift) * sizeof(int2);
+    if (bytes <= ((size_t)64 << 20)) {
+        const std::string keep = t_err;
+        if (pool_get(bytes, plan->device, plan->prow) != UGS_OK) { t_err = keep; plan->prow_failed = true; return UGS_OK; }
+        plan->prow_pooled = true;
+    } else {
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); plan->prow_failed = true; return UGS_OK; }
+        plan->prow.p = p; plan->prow.bytes = bytes; plan->prow.dev = plan->device;
+    }
+    HIP_TRY(ugs_launch_build_prow(plan->dev, plan->nverts, static_cast<int2 *>(plan->prow.p), shift, plan->cus, s));
+    HIP_TRY(hipStreamSynchronize(s));          // once per plan: later calls may come on other streams
+    plan->dev.prow = static_cast<const int2 *>(plan->prow.p);
+    plan->dev.prow_shift = shift;
+    return UGS_OK;
 }
 
 int ensure(PoolBuf &b, size_t bytes, int dev) {
@@ -936,7 +968,7 @@ int ugs_plan_info(const ugs_plan *plan, int k, int64_t *num_graphs, int64_t *num
     if (num_graphs) *num_graphs = plan->G;
     if (num_vertices) *num_vertices = plan->nverts;
     if (nnz) *nnz = plan->nnz;
-    if (device_bytes) *device_bytes = (int64_t)plan->blob_bytes;
+    if (device_bytes) *device_bytes = (int64_t)(plan->blob_bytes + plan->prow.bytes);
     if (tier) *tier = choose_tier(const_cast<ugs_plan *>(plan), k).first;
     return UGS_OK;
 }
@@ -991,6 +1023,8 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
         if (int rc = ensure(plan->work, 4 * sizeof(unsigned long long), plan->device)) return rc;
         HIP_TRY(hipMemsetAsync(plan->work.p, 0, 4 * sizeof(unsigned long long), s));
     }
+    if ((tc.first != UGS_TIER_S && tc.first != UGS_TIER_G) || tc.second >= 0)
+        if (int rc = ensure_prow(plan, s)) return rc;
     uint32_t *cnt = static_cast<uint32_t *>(plan->ovfcnt.p);
     UgsWalkArgs a{};
     a.plan = plan->dev;

@@ -38,19 +38,29 @@
 
 #define UGS_ALIGNED16 __attribute__((aligned(16)))
 
-// Diagnostic build only (-DUGS_STAMPS, never shipped): per-phase shader-cycle totals of the walk kernel, added by lane 0
-// of every group into a buffer of its own (ugs_stamp_buffer); no output value depends on them.
+// Diagnostic build only (-DUGS_STAMPS, never shipped): per-phase shader-cycle totals of the walk kernel.  Lane 0 of every group
+// adds the s_memtime difference of each phase to a per-block LDS array (no waits are inserted: a phase is charged the issue
+// time and the stalls that really happen inside it), flushed to a buffer of its own (ugs_stamp_buffer) at the end of the block;
+// no output value depends on them.  Slots: 0 root + hash reset, 1 scan_row, 2 select (rest), 3 shift + bookkeeping, 4 draw,
+// 5 row output + edge staging, 10/11/12 materialised stage (1 / 2 / more elements per lane), 13/14/15 final stage (same split);
+// slot 16 + i = executions of slot i.
 #ifdef UGS_STAMPS
-__device__ unsigned long long ugs_stamp_buffer[16];
-#define STAMP_DECL unsigned long long st_t0 = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define STAMP_BEGIN() do { __builtin_amdgcn_sched_barrier(0); st_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define STAMP_END(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t1_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); st_acc[i] += t1_ - st_t0; st_t0 = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define STAMP_FLUSH(lane) do { if ((lane) == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&ugs_stamp_buffer[i_], st_acc[i_]); atomicAdd(&ugs_stamp_buffer[8], 1ull); } } while (0)
+__device__ unsigned long long ugs_stamp_buffer[32];
+#define ST_ ws.ST
+#define STAMP_DECL unsigned long long st_t0 = 0
+#define STAMP_BEGIN() do { __builtin_amdgcn_sched_barrier(0); st_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_END(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); \
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&ST_[i], t1_ - st_t0); atomicAdd(&ST_[16 + (i)], 1ull); } st_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+// a routine inside the select phase: its time moves from slot 2 to slot i
+#define STAMP_SUB_BEGIN() __builtin_amdgcn_sched_barrier(0); const unsigned long long sti_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#define STAMP_SUB_END(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); \
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&ST_[i], t1_ - sti_); atomicAdd(&ST_[2], sti_ - t1_); atomicAdd(&ST_[16 + (i)], 1ull); } __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define STAMP_DECL
+#define STAMP_SUB_BEGIN() do {} while (0)
+#define STAMP_SUB_END(i) do {} while (0)
 #define STAMP_BEGIN() do {} while (0)
 #define STAMP_END(i) do {} while (0)
-#define STAMP_FLUSH(lane) do {} while (0)
 #endif
 
 namespace {
@@ -216,6 +226,9 @@ template <class SP> struct Work {
     typename SP::TW *TBL;    // per bucket: (round|pos) -> (size|first) -> start     [bcap]
     uint32_t *HK;            // membership hash (open addressing): vertex id | kFresh | kInS               [hs]
     uint32_t cap, hmask, hlimit;
+#ifdef UGS_STAMPS
+    unsigned long long *ST;  // per-block phase totals (diagnostic build)
+#endif
 };
 
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
@@ -614,9 +627,11 @@ __device__ __forceinline__ void mat_at(const Work<LdsSpace> &ws, const Grp<GS> &
     const uint32_t *OLD = STAGE ? ws.ORD + C::OOLD : ws.D;
     uint32_t *NEW = ws.ORD + C::O;
     constexpr int per = (int)((C::B + GS - 1) / GS);                          // these stages are full: L == B
+    STAMP_SUB_BEGIN();
     if constexpr (GS == 64 && per <= 1) stage_mat_reg(ws, g, OLD, NEW, C::NOLD, C::B, C::M, C::S);
     else if constexpr (GS == 64 && per <= 2) stage_mat_reg2(ws, g, OLD, NEW, C::NOLD, C::B, C::M, C::S);
     else stage_mat<GS, nj_of(per)>(ws, g, OLD, NEW, C::NOLD, C::B, C::M, C::S);
+    STAMP_SUB_END(per <= 1 ? 10 : (per <= 2 ? 11 : 12));
 }
 
 template <int GS, int MAXPER, int STAGE>
@@ -627,7 +642,11 @@ __device__ __forceinline__ uint32_t final_at(const Work<LdsSpace> &ws, const Grp
     constexpr int pmin = (int)((C::NOLD + 1u + GS - 1) / GS), pmax = (int)(((C::B < CAP ? C::B : CAP) + GS - 1) / GS);
     const int per = (int)((c + GS - 1) / GS);
     // a variant serving per in [LO, HI] exists only if the stage's range meets it; the last one that does needs no test
+#ifdef UGS_STAMPS
+#define UGS_FINAL_CASE(LO, HI, CALL) if constexpr (pmin <= (HI) && pmax >= (LO)) { if (pmax <= (HI) || per <= (HI)) { STAMP_SUB_BEGIN(); const uint32_t r_ = CALL; STAMP_SUB_END((HI) <= 1 ? 13 : ((HI) <= 2 ? 14 : 15)); return r_; } }
+#else
 #define UGS_FINAL_CASE(LO, HI, CALL) if constexpr (pmin <= (HI) && pmax >= (LO)) { if (pmax <= (HI) || per <= (HI)) return CALL; }
+#endif
     if constexpr (GS == 64) {
         UGS_FINAL_CASE(1, 1, stage_final_reg(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel))
         UGS_FINAL_CASE(2, 2, stage_final_reg2(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel))
@@ -713,73 +732,108 @@ __device__ __forceinline__ void stage_hits(StageCtx &sc, const Grp<GS> &g, bool 
     sc.ne += (uint32_t)__popcll(im);
 }
 
+// One chunk of an adjacency row: lane holds entry e (neighbour, rank) at CSR position p if `valid`.
 template <int GS, class SP, bool ADD, bool STG>
-__device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, const UgsPlanDev &P, int64_t rbase, uint32_t v,
+__device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g, uint32_t v, uint32_t root_vi, uint32_t size, uint32_t &c,
+                                           uint32_t &hcount, uint32_t &ecount, StageCtx &sc, bool valid, int2 e, int64_t p) {
+    const uint32_t w = valid ? (uint32_t)e.x : 0u;
+    const bool cand = valid && (uint32_t)e.y >= root_vi;
+    uint32_t slot = hash_slot(w, ws.hmask);
+    bool in_s = false;
+    if (ADD) {
+        if (hcount + (uint32_t)__popcll(g.ballot(cand)) > ws.hlimit) return false;
+        // probe: only `seen` and `slot` are carried round the loop; what happened is read off `seen` afterwards
+        uint32_t seen = kKeyMask;                                 // a value no probe returns for a candidate
+        if (cand) {
+            for (uint32_t it = 0; it <= ws.hmask; ++it) {         // the table is never full
+                seen = atomicCAS(&ws.HK[slot], kEmpty, w | kFresh);
+                if (seen == kEmpty || (seen & kKeyMask) == w) break;
+                slot = (slot + 1) & ws.hmask;
+            }
+        }
+        const bool inserted = cand && seen == kEmpty;
+        const bool found = cand && seen != kEmpty && (seen & kKeyMask) == w;
+        in_s = found && (seen & kInS) != 0u;
+        const bool fresh_dup = found && (seen & kFresh) != 0u;
+        SP::sync();
+        // A vertex is NEW if this chunk inserted it; its place in D is that of its FIRST occurrence in the row.  Lanes
+        // that met a key inserted by this very chunk (a repeated neighbour, e.g. both directions of a PyG edge) are
+        // resolved per repeated vertex: the lowest lane holding it represents it.
+        bool first = inserted;
+        uint64_t dupm = g.ballot(fresh_dup);
+        while (dupm) {
+            const int li = __ffsll((long long)dupm) - 1;
+            const uint32_t wi = g.bcast(w, li);
+            const bool mine = cand && w == wi;
+            const uint64_t grp = g.ballot(mine);
+            if (mine) first = g.lane == (__ffsll((long long)grp) - 1);
+            dupm &= ~grp;
+        }
+        if (inserted) ws.HK[slot] = w;                            // the chunk is over for this key: drop kFresh
+        ecount += 2u * (uint32_t)__popcll(g.ballot(in_s && w != v)) + (uint32_t)__popcll(g.ballot(in_s && w == v));
+        if constexpr (STG) { if (sc.on) stage_hits<GS>(sc, g, in_s, w, p, size); }
+        const uint64_t fm = g.ballot(first);
+        const uint32_t nnew = (uint32_t)__popcll(fm);
+        if (c + nnew > ws.cap) return false;
+        if (first) ws.D[c + (uint32_t)__popcll(fm & g.lt_mask())] = w;
+        c += nnew;
+        hcount += nnew;
+        SP::sync();
+    } else {
+        uint32_t seen = kEmpty;
+        if (cand) {
+            for (uint32_t it = 0; it <= ws.hmask; ++it) {
+                seen = ws.HK[slot];
+                if (seen == kEmpty || (seen & kKeyMask) == w) break;
+                slot = (slot + 1) & ws.hmask;
+            }
+        }
+        in_s = cand && seen != kEmpty && (seen & kKeyMask) == w && (seen & kInS) != 0u;
+        ecount += 2u * (uint32_t)__popcll(g.ballot(in_s && w != v)) + (uint32_t)__popcll(g.ballot(in_s && w == v));
+        if constexpr (STG) { if (sc.on) stage_hits<GS>(sc, g, in_s, w, p, size); }
+    }
+    return true;
+}
+
+// row of v through the row pointer (8-lane tier, global-memory tier, plans without padded rows)
+template <int GS, class SP, bool ADD, bool STG>
+__device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, const UgsPlanDev &P, uint32_t v,
                                          uint32_t root_vi, uint32_t size, uint32_t &c, uint32_t &hcount,
                                          uint32_t &ecount, int64_t r0, int64_t r1, StageCtx &sc) {
     for (int64_t base = r0; base < r1; base += GS) {
         const int64_t p = base + g.lane;
-        bool cand = false;
-        uint32_t w = 0;
-        if (p < r1) {
-            int2 e = P.adj[p];
-            w = (uint32_t)e.x;
-            cand = (uint32_t)e.y >= root_vi;
-        }
-        uint32_t slot = hash_slot(w, ws.hmask);
-        bool in_s = false;
-        if (ADD) {
-            if (hcount + (uint32_t)__popcll(g.ballot(cand)) > ws.hlimit) return false;
-            // probe: only `seen` and `slot` are carried round the loop; what happened is read off `seen` afterwards
-            uint32_t seen = kKeyMask;                                 // a value no probe returns for a candidate
-            if (cand) {
-                for (uint32_t it = 0; it <= ws.hmask; ++it) {         // the table is never full
-                    seen = atomicCAS(&ws.HK[slot], kEmpty, w | kFresh);
-                    if (seen == kEmpty || (seen & kKeyMask) == w) break;
-                    slot = (slot + 1) & ws.hmask;
-                }
-            }
-            const bool inserted = cand && seen == kEmpty;
-            const bool found = cand && seen != kEmpty && (seen & kKeyMask) == w;
-            in_s = found && (seen & kInS) != 0u;
-            const bool fresh_dup = found && (seen & kFresh) != 0u;
-            SP::sync();
-            // A vertex is NEW if this chunk inserted it; its place in D is that of its FIRST occurrence in the row.  Lanes
-            // that met a key inserted by this very chunk (a repeated neighbour, e.g. both directions of a PyG edge) are
-            // resolved per repeated vertex: the lowest lane holding it represents it.
-            bool first = inserted;
-            uint64_t dupm = g.ballot(fresh_dup);
-            while (dupm) {
-                const int li = __ffsll((long long)dupm) - 1;
-                const uint32_t wi = g.bcast(w, li);
-                const bool mine = cand && w == wi;
-                const uint64_t grp = g.ballot(mine);
-                if (mine) first = g.lane == (__ffsll((long long)grp) - 1);
-                dupm &= ~grp;
-            }
-            if (inserted) ws.HK[slot] = w;                            // the chunk is over for this key: drop kFresh
-            ecount += 2u * (uint32_t)__popcll(g.ballot(in_s && w != v)) + (uint32_t)__popcll(g.ballot(in_s && w == v));
-            if constexpr (STG) { if (sc.on) stage_hits<GS>(sc, g, in_s, w, p, size); }
-            const uint64_t fm = g.ballot(first);
-            const uint32_t nnew = (uint32_t)__popcll(fm);
-            if (c + nnew > ws.cap) return false;
-            if (first) ws.D[c + (uint32_t)__popcll(fm & g.lt_mask())] = w;
-            c += nnew;
-            hcount += nnew;
-            SP::sync();
-        } else {
-            uint32_t seen = kEmpty;
-            if (cand) {
-                for (uint32_t it = 0; it <= ws.hmask; ++it) {
-                    seen = ws.HK[slot];
-                    if (seen == kEmpty || (seen & kKeyMask) == w) break;
-                    slot = (slot + 1) & ws.hmask;
-                }
-            }
-            in_s = cand && seen != kEmpty && (seen & kKeyMask) == w && (seen & kInS) != 0u;
-            ecount += 2u * (uint32_t)__popcll(g.ballot(in_s && w != v)) + (uint32_t)__popcll(g.ballot(in_s && w == v));
-            if constexpr (STG) { if (sc.on) stage_hits<GS>(sc, g, in_s, w, p, size); }
-        }
+        const bool valid = p < r1;
+        int2 e = make_int2(0, 0);
+        if (valid) e = P.adj[p];
+        if (!scan_chunk<GS, SP, ADD, STG>(ws, g, v, root_vi, size, c, hcount, ecount, sc, valid, e, p)) return false;
+    }
+    return true;
+}
+
+// padded row of v (one walk per wave): `e0` = entry `lane` of the row's block, loaded by the caller as soon as v was known.
+// Lane 0 holds the header (degree, CSR position of the first entry), lanes 1.. the first entries; a longer row continues in adj[].
+__device__ __forceinline__ int2 load_prow(const UgsPlanDev &P, int64_t vrow, int lane) {
+    int2 e = make_int2(0, 0);
+    if (lane < (1 << P.prow_shift)) e = P.prow[(vrow << P.prow_shift) + lane];
+    return e;
+}
+
+template <class SP, bool ADD, bool STG>
+__device__ __forceinline__ bool scan_prow(const Work<SP> &ws, const Grp<64> &g, const UgsPlanDev &P, uint32_t v,
+                                          uint32_t root_vi, uint32_t size, uint32_t &c, uint32_t &hcount,
+                                          uint32_t &ecount, int2 e0, StageCtx &sc) {
+    const uint32_t deg = g.bcast((uint32_t)e0.x, 0);
+    const int64_t start = (int64_t)g.bcast((uint32_t)e0.y, 0);
+    const uint32_t inl = (1u << P.prow_shift) - 1u;                              // entries held by the block itself
+    const uint32_t n0 = deg < inl ? deg : inl;
+    if (n0 && !scan_chunk<64, SP, ADD, STG>(ws, g, v, root_vi, size, c, hcount, ecount, sc, (uint32_t)(g.lane - 1) < n0, e0, start + g.lane - 1)) return false;
+    const int64_t r1 = start + deg;
+    for (int64_t base = start + inl; base < r1; base += 64) {
+        const int64_t p = base + g.lane;
+        const bool valid = p < r1;
+        int2 e = make_int2(0, 0);
+        if (valid) e = P.adj[p];
+        if (!scan_chunk<64, SP, ADD, STG>(ws, g, v, root_vi, size, c, hcount, ecount, sc, valid, e, p)) return false;
     }
     return true;
 }
@@ -814,9 +868,10 @@ __device__ __forceinline__ void stage_flush(uint32_t ne, const Grp<64> &g, const
 }
 
 // One walk.  Returns false on workspace overflow (the row is then redone by the next tier).
-template <int GS, class SP, int MAXPER>
+template <int GS, class SP, int MAXPER, bool PAD>
 __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, const UgsWalkArgs &a, int64_t row_rel,
                                         uint32_t *SV /* [UGS_KMAX] group-private */, uint4 *EL /* [UGS_STAGE_ENTRIES] or null */) {
+    static_assert(!PAD || GS == 64, "padded rows are read by a whole wave");
     constexpr bool STG = GS == 64 && sizeof(typename SP::TW) == 4;             // one walk per wave, LDS workspace
     StageCtx sc;
     sc.EL = EL; sc.ne = 0u; sc.on = STG && a.stage != nullptr && EL != nullptr;
@@ -863,9 +918,18 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
     uint32_t size = 1, c = 0, hcount = 1, ecount = 0;
     int nvalid = 0;           // leading stages of the order computation that are still valid
     STAMP_END(0);
-    int64_t r0 = g.uni(P.rowptr[gd.rbase + root_v]), r1 = g.uni(P.rowptr[gd.rbase + root_v + 1]);
-    bool ok = (k > 1) ? scan_row<GS, SP, true, STG>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, ecount, r0, r1, sc)
-                      : scan_row<GS, SP, false, STG>(ws, g, P, gd.rbase, root_v, root_vi, size, c, hcount, ecount, r0, r1, sc);
+    int64_t r0 = 0, r1 = 0;
+    int2 e0 = make_int2(0, 0);
+    bool ok;
+    if constexpr (PAD) {
+        e0 = load_prow(P, gd.vbase + root_v, g.lane);
+        ok = (k > 1) ? scan_prow<SP, true, STG>(ws, g, P, root_v, root_vi, size, c, hcount, ecount, e0, sc)
+                     : scan_prow<SP, false, STG>(ws, g, P, root_v, root_vi, size, c, hcount, ecount, e0, sc);
+    } else {
+        r0 = g.uni(P.rowptr[gd.rbase + root_v]); r1 = g.uni(P.rowptr[gd.rbase + root_v + 1]);
+        ok = (k > 1) ? scan_row<GS, SP, true, STG>(ws, g, P, root_v, root_vi, size, c, hcount, ecount, r0, r1, sc)
+                     : scan_row<GS, SP, false, STG>(ws, g, P, root_v, root_vi, size, c, hcount, ecount, r0, r1, sc);
+    }
     STAMP_END(1);
     if (!ok) return false;
     for (int step = 1; step < k; ++step) {
@@ -873,9 +937,13 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
         const uint32_t rsel = g.uni(mod64_by(rng.next(), c));
         STAMP_END(4);
         const uint32_t w = select_any<GS, MAXPER>(ws, g, c, rsel, nvalid);
-        r0 = P.rowptr[gd.rbase + w];               // issued now, consumed after the candidate list has been updated
-        r1 = P.rowptr[gd.rbase + w + 1];
-        r0 = g.uni(r0); r1 = g.uni(r1);
+        if constexpr (PAD) {
+            e0 = load_prow(P, gd.vbase + w, g.lane);                  // the row itself: issued now, consumed after the candidate list has been updated
+        } else {
+            r0 = P.rowptr[gd.rbase + w];
+            r1 = P.rowptr[gd.rbase + w + 1];
+            r0 = g.uni(r0); r1 = g.uni(r1);
+        }
         STAMP_END(2);
         // move w from the candidates to the sample: drop it from D keeping the order of the others
         uint32_t q = c;
@@ -918,8 +986,12 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
         size += 1;
         SP::sync();
         STAMP_END(3);
-        ok = (step < k - 1) ? scan_row<GS, SP, true, STG>(ws, g, P, gd.rbase, w, root_vi, size, c, hcount, ecount, r0, r1, sc)
-                            : scan_row<GS, SP, false, STG>(ws, g, P, gd.rbase, w, root_vi, size, c, hcount, ecount, r0, r1, sc);
+        if constexpr (PAD)
+            ok = (step < k - 1) ? scan_prow<SP, true, STG>(ws, g, P, w, root_vi, size, c, hcount, ecount, e0, sc)
+                                : scan_prow<SP, false, STG>(ws, g, P, w, root_vi, size, c, hcount, ecount, e0, sc);
+        else
+            ok = (step < k - 1) ? scan_row<GS, SP, true, STG>(ws, g, P, w, root_vi, size, c, hcount, ecount, r0, r1, sc)
+                                : scan_row<GS, SP, false, STG>(ws, g, P, w, root_vi, size, c, hcount, ecount, r0, r1, sc);
         STAMP_END(1);
         if (!ok) return false;
     }
@@ -944,7 +1016,6 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
         }
     }
     STAMP_END(5);
-    STAMP_FLUSH(g.lane);
     return true;
 }
 
@@ -966,7 +1037,7 @@ template <int CAP> struct TierCfg {
 // admits 18 one-wave blocks per CU (5,5,4,4 per SIMD).  With a STATIC split of the rows 18 blocks/CU was slower than 16
 // (10.63 vs 10.43 ms: a launch ended with the waves of the fuller SIMDs); with the shared work counter the extra waves are
 // pure throughput: 8.81 -> 8.51 ms.  Spilling further to reach more waves costs more than it brings (30 % in an early build).
-template <int GS, int CAP, int BLOCK>
+template <int GS, int CAP, int BLOCK, bool PAD>
 __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP <= 64 || CAP == 1024 ? 2 : 1)) void ugs_walk_lds(UgsWalkArgs a) {
     using Cfg = TierCfg<CAP>;
     constexpr int GROUPS = BLOCK / GS;
@@ -986,6 +1057,13 @@ __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP <= 64 ||
     ws.cap = CAP;
     ws.hmask = Cfg::HS - 1;
     ws.hlimit = Cfg::HLIMIT;
+#ifdef UGS_STAMPS
+    __shared__ unsigned long long stamps[32];
+    if (threadIdx.x < 32) stamps[threadIdx.x] = 0ull;
+    __syncthreads();
+    ws.ST = stamps;
+    struct Flush { unsigned long long *st; __device__ ~Flush() { __syncthreads(); if (threadIdx.x < 32) atomicAdd(&ugs_stamp_buffer[threadIdx.x], st[threadIdx.x]); } } flush_{stamps};
+#endif
     const int64_t total = a.in_list ? (int64_t)*a.in_count : a.row_count;
     const int64_t ngroups = (int64_t)gridDim.x * GROUPS;
     if (a.work_next) {
@@ -1000,7 +1078,7 @@ __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP <= 64 ||
             const int64_t end = it + kWorkChunk < total ? it + kWorkChunk : total;
             for (; it < end; ++it) {
                 const int64_t row_rel = a.in_list ? a.in_list[it] : it;
-                if (!do_walk<GS, LdsSpace, (CAP + GS - 1) / GS>(ws, g, a, row_rel, SV, EL)) {
+                if (!do_walk<GS, LdsSpace, (CAP + GS - 1) / GS, PAD>(ws, g, a, row_rel, SV, EL)) {
                     if (g.lane == 0 && a.ovf_list) { uint32_t pos = atomicAdd(a.ovf_count, 1u); a.ovf_list[pos] = row_rel; }
                 }
             }
@@ -1013,10 +1091,29 @@ __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP <= 64 ||
     }
     for (int64_t it = (int64_t)blockIdx.x * GROUPS + gib; it < total; it += ngroups) {
         const int64_t row_rel = a.in_list ? a.in_list[it] : it;
-        if (!do_walk<GS, LdsSpace, (CAP + GS - 1) / GS>(ws, g, a, row_rel, SV, EL)) {
+        if (!do_walk<GS, LdsSpace, (CAP + GS - 1) / GS, PAD>(ws, g, a, row_rel, SV, EL)) {
             if (g.lane == 0 && a.ovf_list) { uint32_t pos = atomicAdd(a.ovf_count, 1u); a.ovf_list[pos] = row_rel; }
         }
     }
+}
+
+// Padded rows (ugs_device.h): entry l of the block of plan vertex R.  One thread per entry; runs once per plan.
+__global__ __launch_bounds__(256) void ugs_build_prow(UgsPlanDev P, int64_t num_vertices, int2 *prow, int shift) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t R = idx >> shift;
+    if (R >= num_vertices) return;
+    const int l = (int)(idx & ((1 << shift) - 1));
+    int64_t lo = 0, hi = P.num_graphs - 1;                      // last graph whose first vertex is <= R (degenerate graphs own none)
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (P.graphs[mid].vbase <= R) lo = mid; else hi = mid - 1;
+    }
+    const int64_t rb = P.graphs[lo].rbase, v = R - P.graphs[lo].vbase;
+    const int64_t start = P.rowptr[rb + v], deg = P.rowptr[rb + v + 1] - start;
+    int2 e = make_int2(0, 0);
+    if (l == 0) e = make_int2((int)deg, (int)start);
+    else if (l - 1 < deg) e = P.adj[start + l - 1];
+    prow[idx] = e;
 }
 
 // last tier: workspace in global memory, one wave per walk, any candidate-set size up to gcap
@@ -1035,10 +1132,14 @@ __global__ __launch_bounds__(64) void ugs_walk_global(UgsWalkArgs a) {
     ws.cap = (uint32_t)a.gcap;
     ws.hmask = (uint32_t)a.ghs - 1u;
     ws.hlimit = (uint32_t)a.ghs / 4u * 3u;
+#ifdef UGS_STAMPS
+    __shared__ unsigned long long stamps[32];      // the global tier's phases are not reported
+    ws.ST = stamps;
+#endif
     const int64_t total = a.in_list ? (int64_t)*a.in_count : a.row_count;
     for (int64_t it = blockIdx.x; it < total; it += gridDim.x) {
         const int64_t row_rel = a.in_list ? a.in_list[it] : it;
-        if (!do_walk<64, GlbSpace, 0>(ws, g, a, row_rel, SV, nullptr)) {
+        if (!do_walk<64, GlbSpace, 0, false>(ws, g, a, row_rel, SV, nullptr)) {
             // cannot happen when gcap covers the graph's bound; mark the row so the host can report it
             if (g.lane == 0 && a.ovf_list) { uint32_t pos = atomicAdd(a.ovf_count, 1u); a.ovf_list[pos] = row_rel; }
         }
@@ -1257,38 +1358,6 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
     }
 }
 
-#ifdef UGS_PROBE   // diagnostic build only: one kernel per hot routine, to read their instruction counts from the ISA
-template <int NJ> __global__ __launch_bounds__(64, 4) void probe_final(uint32_t *out, uint32_t c, uint32_t rsel, int fs) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[TierCfg<448>::WORDS];
-    Grp<64> g; g.init();
-    Work<LdsSpace> ws; ws.D = lds; ws.ORD = ws.D + 448; ws.AUX = nullptr; ws.TBL = ws.ORD + TierCfg<448>::ORDW; ws.HK = ws.TBL + TierCfg<448>::BCAP_A;
-    ws.cap = 448; ws.hmask = 511; ws.hlimit = 448;
-    out[threadIdx.x] = stage_final<64, NJ>(ws, g, ws.ORD + d_chain.O[fs - 1], d_chain.B[fs - 1], c, d_chain.B[fs], d_chain.M[fs], d_chain.S[fs], rsel);
-}
-template <int NJ> __global__ __launch_bounds__(64, 4) void probe_mat(uint32_t *out, int stage) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[TierCfg<448>::WORDS];
-    Grp<64> g; g.init();
-    Work<LdsSpace> ws; ws.D = lds; ws.ORD = ws.D + 448; ws.AUX = nullptr; ws.TBL = ws.ORD + TierCfg<448>::ORDW; ws.HK = ws.TBL + TierCfg<448>::BCAP_A;
-    ws.cap = 448; ws.hmask = 511; ws.hlimit = 448;
-    stage_mat<64, NJ>(ws, g, ws.ORD + d_chain.O[stage - 1], ws.ORD + d_chain.O[stage], d_chain.B[stage - 1], d_chain.B[stage], d_chain.M[stage], d_chain.S[stage]);
-    out[threadIdx.x] = ws.ORD[threadIdx.x];
-}
-__global__ __launch_bounds__(64, 4) void probe_scan_row(uint32_t *out, UgsPlanDev P, uint32_t v, uint32_t root_vi, int64_t r0, int64_t r1) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[TierCfg<448>::WORDS];
-    Grp<64> g; g.init();
-    Work<LdsSpace> ws; ws.D = lds; ws.ORD = ws.D + 448; ws.AUX = nullptr; ws.TBL = ws.ORD + TierCfg<448>::ORDW; ws.HK = ws.TBL + TierCfg<448>::BCAP_A;
-    ws.cap = 448; ws.hmask = 511; ws.hlimit = 448;
-    uint32_t c = 5, hcount = 6, ecount = 0;
-    bool ok = scan_row<64, LdsSpace, true>(ws, g, P, 0, v, root_vi, 3, c, hcount, ecount, r0, r1);
-    out[threadIdx.x] = c + hcount + ecount + (ok ? 1u : 0u);
-}
-template __global__ void probe_final<1>(uint32_t *, uint32_t, uint32_t, int);
-template __global__ void probe_final<3>(uint32_t *, uint32_t, uint32_t, int);
-template __global__ void probe_final<5>(uint32_t *, uint32_t, uint32_t, int);
-template __global__ void probe_mat<1>(uint32_t *, int);
-template __global__ void probe_mat<3>(uint32_t *, int);
-template __global__ void probe_mat<5>(uint32_t *, int);
-#endif
 
 }  // namespace
 
@@ -1296,9 +1365,9 @@ template __global__ void probe_mat<5>(uint32_t *, int);
 // launchers
 // ------------------------------------------------------------------------------------------------------------------
 #ifdef UGS_STAMPS
-extern "C" int ugs_debug_read_stamps(unsigned long long *out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ugs_stamp_buffer), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ugs_stamp_buffer), z, sizeof(z)) != hipSuccess) return -1; }
+extern "C" int ugs_debug_read_stamps(unsigned long long *out32, int reset) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(ugs_stamp_buffer), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ugs_stamp_buffer), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #endif
@@ -1322,13 +1391,15 @@ uint32_t ugs_chain_at_least(int64_t c, int *index_out) {   // smallest chain val
 
 template <int GS, int CAP, int BLOCK>
 static hipError_t launch_lds(const UgsWalkArgs &a, int cus, int blocks_per_cu, hipStream_t s, UgsLaunchInfo *info, const char *name) {
+    constexpr bool kCanPad = GS == 64;
     constexpr int GROUPS = BLOCK / GS;
     const int64_t work = a.in_list ? (int64_t)cus * blocks_per_cu * GROUPS : a.row_count;   // list length unknown on the host
     int64_t grid = (work + GROUPS - 1) / GROUPS;
     const int64_t cap = (int64_t)cus * blocks_per_cu;
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((ugs_walk_lds<GS, CAP, BLOCK>), dim3((unsigned)grid), dim3(BLOCK), 0, s, a);
+    if (kCanPad && a.plan.prow) hipLaunchKernelGGL((ugs_walk_lds<GS, CAP, BLOCK, kCanPad>), dim3((unsigned)grid), dim3(BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((ugs_walk_lds<GS, CAP, BLOCK, false>), dim3((unsigned)grid), dim3(BLOCK), 0, s, a);
     if (info) { info->name = name; info->grid = (int)grid; info->block = BLOCK; info->lds_bytes = GROUPS * TierCfg<CAP>::WORDS * 4; }
     return hipGetLastError();
 }
@@ -1349,6 +1420,14 @@ hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, hipStream_t 
         return hipGetLastError();
     }
     }
+}
+
+hipError_t ugs_launch_build_prow(const UgsPlanDev &plan, int64_t num_vertices, int2 *prow, int shift, int cus, hipStream_t s) {
+    (void)cus;
+    const int64_t total = num_vertices << shift;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ugs_build_prow, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, plan, num_vertices, prow, shift);
+    return hipGetLastError();
 }
 
 hipError_t ugs_launch_scan(const uint32_t *counts, int64_t rows, int64_t *edge_ptr, int64_t *block_tmp, hipStream_t s) {
