@@ -53,12 +53,14 @@ __device__ unsigned long long ugs_stamp_buffer[32];
     if ((threadIdx.x & 63) == 0) { atomicAdd(&ST_[i], t1_ - st_t0); atomicAdd(&ST_[16 + (i)], 1ull); } st_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 // a routine inside the select phase: its time moves from slot 2 to slot i
 #define STAMP_SUB_BEGIN() __builtin_amdgcn_sched_barrier(0); const unsigned long long sti_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
-#define STAMP_SUB_END(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); \
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&ST_[i], t1_ - sti_); atomicAdd(&ST_[2], sti_ - t1_); atomicAdd(&ST_[16 + (i)], 1ull); } __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_SUB_END_OF(parent, i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); \
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&ST_[i], t1_ - sti_); atomicAdd(&ST_[parent], sti_ - t1_); atomicAdd(&ST_[16 + (i)], 1ull); } __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_SUB_END(i) STAMP_SUB_END_OF(2, i)
 #else
 #define STAMP_DECL
 #define STAMP_SUB_BEGIN() do {} while (0)
 #define STAMP_SUB_END(i) do {} while (0)
+#define STAMP_SUB_END_OF(parent, i) do {} while (0)
 #define STAMP_BEGIN() do {} while (0)
 #define STAMP_END(i) do {} while (0)
 #endif
@@ -111,8 +113,9 @@ __device__ __forceinline__ uint32_t mod_small(uint32_t y, uint32_t c, uint32_t M
     r = r >= c ? r - c : r;
     return r;
 }
+template <bool SMALL>       // SMALL: the caller guarantees c < 2^16 (every LDS tier: c <= its candidate capacity)
 __device__ __forceinline__ uint32_t mod64_by(uint64_t x, uint32_t c) {
-    if (c >= 65536u) return (uint32_t)(x % (uint64_t)c);
+    if constexpr (!SMALL) { if (c >= 65536u) return (uint32_t)(x % (uint64_t)c); }
     const uint32_t M = 0xFFFFFFFFu / c;
     uint32_t r32 = 0xFFFFFFFFu - M * c + 1u;            // (2^32 - 1) mod c + 1, in [1, c]
     r32 = r32 == c ? 0u : r32;                          // 2^32 mod c
@@ -209,10 +212,12 @@ template <int GS> struct Grp {
 // memory-space policies of the per-walk workspace --------------------------------------------------------------------
 struct LdsSpace {       // LDS: one wave's LDS operations are serviced in issue order; only the compiler must be fenced
     using TW = uint32_t; using TA = uint16_t;
+    using TO = uint16_t;                       // stage orders hold POSITIONS in D (the key is one more LDS read away)
     static __device__ __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 };
 struct GlbSpace {       // global-memory fallback: agent-scope fence between phases (rare, correctness-first tier)
     using TW = unsigned long long; using TA = uint32_t;
+    using TO = uint32_t;                       // stage orders hold the vertices themselves
     static constexpr int SH = 32;
     static constexpr TW PMASK = 0xFFFFFFFFull, FLAG = 1ull << 63;
     static constexpr TA UNASSIGNED = 0xFFFFFFFFu;
@@ -221,7 +226,9 @@ struct GlbSpace {       // global-memory fallback: agent-scope fence between pha
 
 template <class SP> struct Work {
     uint32_t *D;             // distinct candidates, first-insertion order           [cap]
-    uint32_t *ORD;           // materialised order of every non-final stage, stage i at ORD + d_chain.O[i]
+    typename SP::TO *ORD;    // materialised order of every non-final stage, stage i at ORD + d_chain.O[i] (LDS tiers: positions in
+                             // D, 16 bits each -- a stage's order stays valid while the removed candidate lies behind its prefix, and
+                             // so do the positions; global-memory tier: the vertices)
     typename SP::TA *AUX;    // per element: position inside its bucket (generic path only)   [cap]
     typename SP::TW *TBL;    // per bucket: (round|pos) -> (size|first) -> start     [bcap]
     uint32_t *HK;            // membership hash (open addressing): vertex id | kFresh | kInS               [hs]
@@ -232,6 +239,8 @@ template <class SP> struct Work {
 };
 
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+
+struct Pick { uint32_t w, q; };   // chosen vertex and its position in D (q = c: not known, the caller searches D)
 
 __device__ __forceinline__ uint32_t hash_slot(uint32_t w, uint32_t mask) { return (w * 2654435761u >> 7) & mask; }
 
@@ -331,11 +340,11 @@ __device__ __forceinline__ uint32_t select_in_order(const Work<SP> &ws, const Gr
 // No loop over rounds: nine LDS round trips whatever the bucket sizes (a bucket of more than UNR members takes a short
 // extra loop).
 template <int GS, int NJ>
-__device__ __forceinline__ void stage_mat(const Work<LdsSpace> &ws, const Grp<GS> &g, const uint32_t *OLD, uint32_t *NEW,
+__device__ __forceinline__ void stage_mat(const Work<LdsSpace> &ws, const Grp<GS> &g, const uint16_t *OLD, uint16_t *NEW,
                                           uint32_t n_old, uint32_t B, uint32_t M, uint32_t S) {
     constexpr int UNR = NJ <= 5 ? 6 : 4;
     const uint32_t t0 = (uint32_t)g.lane * NJ;
-    uint32_t key[NJ], bk[NJ];
+    uint32_t pos[NJ], bk[NJ];                                                   // position in D; the key is only needed for the bucket
     bool valid[NJ];
     {
         uint4 *T4 = reinterpret_cast<uint4 *>(ws.TBL);
@@ -346,9 +355,12 @@ __device__ __forceinline__ void stage_mat(const Work<LdsSpace> &ws, const Grp<GS
     for (int j = 0; j < NJ; ++j) {
         const uint32_t t = t0 + j;
         valid[j] = t < B;
-        key[j] = 0u;
-        if (valid[j]) key[j] = (t < n_old) ? OLD[t] : ws.D[t];
+        pos[j] = t;
+        if (valid[j] && t < n_old) pos[j] = OLD[t];
     }
+    uint32_t key[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { key[j] = 0u; if (valid[j]) key[j] = ws.D[pos[j]]; }
     LdsSpace::sync();
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -408,7 +420,7 @@ __device__ __forceinline__ void stage_mat(const Work<LdsSpace> &ws, const Grp<GS
     LdsSpace::sync();
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
-        if (valid[j]) NEW[st[j] + rho[j]] = key[j];
+        if (valid[j]) NEW[st[j] + rho[j]] = (uint16_t)pos[j];
     LdsSpace::sync();
 }
 
@@ -442,27 +454,29 @@ __device__ __forceinline__ uint32_t rank_in_registers(const Grp<64> &g, bool val
     return start + above;
 }
 
-__device__ __forceinline__ void stage_mat_reg(const Work<LdsSpace> &ws, const Grp<64> &g, const uint32_t *OLD, uint32_t *NEW,
+__device__ __forceinline__ void stage_mat_reg(const Work<LdsSpace> &ws, const Grp<64> &g, const uint16_t *OLD, uint16_t *NEW,
                                               uint32_t n_old, uint32_t B, uint32_t M, uint32_t S) {
     const uint32_t t = (uint32_t)g.lane;
     const bool valid = t < B;
-    uint32_t key = 0u;
-    if (valid) key = (t < n_old) ? OLD[t] : ws.D[t];
+    uint32_t pos = t, key = 0u;
+    if (valid && t < n_old) pos = OLD[t];
+    if (valid) key = ws.D[pos];
     const uint32_t rank = rank_in_registers(g, valid, mod_magic(key, B, M, S), S + 1u);
-    if (valid) NEW[rank] = key;
+    if (valid) NEW[rank] = (uint16_t)pos;
     LdsSpace::sync();
 }
 
-__device__ __forceinline__ uint32_t stage_final_reg(const Work<LdsSpace> &ws, const Grp<64> &g, const uint32_t *OLD, uint32_t n_old,
-                                                    uint32_t L, uint32_t B, uint32_t M, uint32_t S, uint32_t rsel) {
+__device__ __forceinline__ Pick stage_final_reg(const Work<LdsSpace> &ws, const Grp<64> &g, const uint16_t *OLD, uint32_t n_old,
+                                                uint32_t L, uint32_t B, uint32_t M, uint32_t S, uint32_t rsel) {
     const uint32_t t = (uint32_t)g.lane;
     const bool valid = t < L;
-    uint32_t key = 0u;
-    if (valid) key = (t < n_old) ? OLD[t] : ws.D[t];
+    uint32_t pos = t, key = 0u;
+    if (valid && t < n_old) pos = OLD[t];
+    if (valid) key = ws.D[pos];
     const uint32_t rank = rank_in_registers(g, valid, mod_magic(key, B, M, S), S + 1u);
     const uint64_t hm = __ballot(valid && rank == rsel);
     const int src = hm ? (__ffsll((long long)hm) - 1) : 0;
-    return g.bcast(key, src);
+    return Pick{g.bcast(key, src), g.bcast(pos, src)};
 }
 
 // The same for 65..128 elements: lane l holds positions l (slot 0) and 64 + l (slot 1); four mate masks (own slot x other
@@ -507,41 +521,47 @@ __device__ __forceinline__ Rank2 rank2_in_registers(const Grp<64> &g, bool valid
     return r;
 }
 
-__device__ __forceinline__ void stage_mat_reg2(const Work<LdsSpace> &ws, const Grp<64> &g, const uint32_t *OLD, uint32_t *NEW,
+__device__ __forceinline__ void stage_mat_reg2(const Work<LdsSpace> &ws, const Grp<64> &g, const uint16_t *OLD, uint16_t *NEW,
                                                uint32_t n_old, uint32_t B, uint32_t M, uint32_t S) {
     const uint32_t t0 = (uint32_t)g.lane, t1 = t0 + 64u;
     const bool valid1 = t1 < B;
-    const uint32_t key0 = (t0 < n_old) ? OLD[t0] : ws.D[t0];
+    uint32_t pos0 = t0, pos1 = t1;
+    if (t0 < n_old) pos0 = OLD[t0];
+    if (valid1 && t1 < n_old) pos1 = OLD[t1];
+    const uint32_t key0 = ws.D[pos0];
     uint32_t key1 = 0u;
-    if (valid1) key1 = (t1 < n_old) ? OLD[t1] : ws.D[t1];
+    if (valid1) key1 = ws.D[pos1];
     const Rank2 r = rank2_in_registers(g, valid1, mod_magic(key0, B, M, S), mod_magic(key1, B, M, S), S + 1u);
-    NEW[r.r0] = key0;
-    if (valid1) NEW[r.r1] = key1;
+    NEW[r.r0] = (uint16_t)pos0;
+    if (valid1) NEW[r.r1] = (uint16_t)pos1;
     LdsSpace::sync();
 }
 
-__device__ __forceinline__ uint32_t stage_final_reg2(const Work<LdsSpace> &ws, const Grp<64> &g, const uint32_t *OLD, uint32_t n_old,
-                                                     uint32_t L, uint32_t B, uint32_t M, uint32_t S, uint32_t rsel) {
+__device__ __forceinline__ Pick stage_final_reg2(const Work<LdsSpace> &ws, const Grp<64> &g, const uint16_t *OLD, uint32_t n_old,
+                                                 uint32_t L, uint32_t B, uint32_t M, uint32_t S, uint32_t rsel) {
     const uint32_t t0 = (uint32_t)g.lane, t1 = t0 + 64u;
     const bool valid1 = t1 < L;
-    const uint32_t key0 = (t0 < n_old) ? OLD[t0] : ws.D[t0];
+    uint32_t pos0 = t0, pos1 = t1;
+    if (t0 < n_old) pos0 = OLD[t0];
+    if (valid1 && t1 < n_old) pos1 = OLD[t1];
+    const uint32_t key0 = ws.D[pos0];
     uint32_t key1 = 0u;
-    if (valid1) key1 = (t1 < n_old) ? OLD[t1] : ws.D[t1];
+    if (valid1) key1 = ws.D[pos1];
     const Rank2 r = rank2_in_registers(g, valid1, mod_magic(key0, B, M, S), mod_magic(key1, B, M, S), S + 1u);
     const bool h0 = r.r0 == rsel, h1 = valid1 && r.r1 == rsel;
     const uint64_t hm = __ballot(h0 || h1);
     const int src = hm ? (__ffsll((long long)hm) - 1) : 0;
-    return g.bcast(h0 ? key0 : key1, src);
+    return Pick{g.bcast(h0 ? key0 : key1, src), g.bcast(h0 ? pos0 : pos1, src)};
 }
 
 // The LAST stage only has to name the element at iteration position `rsel`, so nothing is ranked or materialised:
 // one atomicMin (first position of every bucket) and one atomicAdd (its size) on the same word, a scan of the sizes
 // over the bucket leaders to find the bucket that holds position rsel, and ballots among that bucket's few members.
 template <int GS, int NJ>
-__device__ __forceinline__ uint32_t stage_final(const Work<LdsSpace> &ws, const Grp<GS> &g, const uint32_t *OLD, uint32_t n_old,
-                                                uint32_t L, uint32_t B, uint32_t M, uint32_t S, uint32_t rsel) {
+__device__ __forceinline__ Pick stage_final(const Work<LdsSpace> &ws, const Grp<GS> &g, const uint16_t *OLD, uint32_t n_old,
+                                            uint32_t L, uint32_t B, uint32_t M, uint32_t S, uint32_t rsel) {
     const uint32_t t0 = (uint32_t)g.lane * NJ;
-    uint32_t key[NJ], bk[NJ];
+    uint32_t pos[NJ], bk[NJ];                                                   // position in D; the key is only needed for the bucket
     bool valid[NJ];
     {
         uint4 *T4 = reinterpret_cast<uint4 *>(ws.TBL);
@@ -552,14 +572,19 @@ __device__ __forceinline__ uint32_t stage_final(const Work<LdsSpace> &ws, const 
     for (int j = 0; j < NJ; ++j) {
         const uint32_t t = t0 + j;
         valid[j] = t < L;
-        key[j] = 0u;
-        if (valid[j]) key[j] = (t < n_old) ? OLD[t] : ws.D[t];
+        pos[j] = t;
+        if (valid[j] && t < n_old) pos[j] = OLD[t];
     }
-    LdsSpace::sync();
+    {
+        uint32_t key[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        bk[j] = mod_magic(key[j], B, M, S);
-        atomicMin(&ws.TBL[bk[j]], valid[j] ? t0 + j : 0xFFFFu);
+        for (int j = 0; j < NJ; ++j) { key[j] = 0u; if (valid[j]) key[j] = ws.D[pos[j]]; }
+        LdsSpace::sync();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            bk[j] = mod_magic(key[j], B, M, S);
+            atomicMin(&ws.TBL[bk[j]], valid[j] ? t0 + j : 0xFFFFu);
+        }
     }
     LdsSpace::sync();
 #pragma unroll
@@ -597,12 +622,13 @@ __device__ __forceinline__ uint32_t stage_final(const Work<LdsSpace> &ws, const 
     uint32_t mine = 0u, own_above = 0u;
 #pragma unroll
     for (int j = NJ - 1; j >= 0; --j) {
-        if (cand[j]) { if (higher + own_above == off) { have = true; mine = key[j]; } own_above += 1u; }
+        if (cand[j]) { if (higher + own_above == off) { have = true; mine = pos[j]; } own_above += 1u; }
     }
     const uint64_t mk = g.ballot(have);
     const int src = mk ? (__ffsll((long long)mk) - 1) : 0;
     LdsSpace::sync();
-    return g.bcast(mine, src);
+    const uint32_t q = g.bcast(mine, src);
+    return Pick{g.uni(ws.D[q]), q};
 }
 
 // LDS tiers: iteration-order selection with the register-resident stages; `nvalid` = number of leading stages whose
@@ -624,8 +650,8 @@ template <int STAGE> struct ChainAt {
 template <int GS, int MAXPER, int STAGE>
 __device__ __forceinline__ void mat_at(const Work<LdsSpace> &ws, const Grp<GS> &g) {
     using C = ChainAt<STAGE>;
-    const uint32_t *OLD = STAGE ? ws.ORD + C::OOLD : ws.D;
-    uint32_t *NEW = ws.ORD + C::O;
+    const uint16_t *OLD = ws.ORD + C::OOLD;                                   // stage 0 has no predecessor (NOLD = 0: never read)
+    uint16_t *NEW = ws.ORD + C::O;
     constexpr int per = (int)((C::B + GS - 1) / GS);                          // these stages are full: L == B
     STAMP_SUB_BEGIN();
     if constexpr (GS == 64 && per <= 1) stage_mat_reg(ws, g, OLD, NEW, C::NOLD, C::B, C::M, C::S);
@@ -635,15 +661,15 @@ __device__ __forceinline__ void mat_at(const Work<LdsSpace> &ws, const Grp<GS> &
 }
 
 template <int GS, int MAXPER, int STAGE>
-__device__ __forceinline__ uint32_t final_at(const Work<LdsSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel) {
+__device__ __forceinline__ Pick final_at(const Work<LdsSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel) {
     using C = ChainAt<STAGE>;
-    const uint32_t *OLD = STAGE ? ws.ORD + C::OOLD : ws.D;
+    const uint16_t *OLD = ws.ORD + C::OOLD;
     constexpr uint32_t CAP = (uint32_t)(MAXPER * GS);
     constexpr int pmin = (int)((C::NOLD + 1u + GS - 1) / GS), pmax = (int)(((C::B < CAP ? C::B : CAP) + GS - 1) / GS);
     const int per = (int)((c + GS - 1) / GS);
     // a variant serving per in [LO, HI] exists only if the stage's range meets it; the last one that does needs no test
 #ifdef UGS_STAMPS
-#define UGS_FINAL_CASE(LO, HI, CALL) if constexpr (pmin <= (HI) && pmax >= (LO)) { if (pmax <= (HI) || per <= (HI)) { STAMP_SUB_BEGIN(); const uint32_t r_ = CALL; STAMP_SUB_END((HI) <= 1 ? 13 : ((HI) <= 2 ? 14 : 15)); return r_; } }
+#define UGS_FINAL_CASE(LO, HI, CALL) if constexpr (pmin <= (HI) && pmax >= (LO)) { if (pmax <= (HI) || per <= (HI)) { STAMP_SUB_BEGIN(); const Pick r_ = CALL; STAMP_SUB_END((HI) <= 1 ? 13 : ((HI) <= 2 ? 14 : 15)); return r_; } }
 #else
 #define UGS_FINAL_CASE(LO, HI, CALL) if constexpr (pmin <= (HI) && pmax >= (LO)) { if (pmax <= (HI) || per <= (HI)) return CALL; }
 #endif
@@ -663,7 +689,7 @@ __device__ __forceinline__ uint32_t final_at(const Work<LdsSpace> &ws, const Grp
     UGS_FINAL_CASE(14, 17, (stage_final<GS, 17>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
     UGS_FINAL_CASE(18, 1 << 20, (stage_final<GS, 33>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
 #undef UGS_FINAL_CASE
-    return 0u;
+    return Pick{0u, 0u};
 }
 
 template <int GS, int MAXPER, int STAGE, int NST>
@@ -675,7 +701,7 @@ __device__ __forceinline__ void materialise_from(const Work<LdsSpace> &ws, const
 }
 
 template <int GS, int MAXPER, int STAGE, int NST>
-__device__ __forceinline__ uint32_t final_from(const Work<LdsSpace> &ws, const Grp<GS> &g, int fs, uint32_t c, uint32_t rsel) {
+__device__ __forceinline__ Pick final_from(const Work<LdsSpace> &ws, const Grp<GS> &g, int fs, uint32_t c, uint32_t rsel) {
     if constexpr (STAGE < NST) {
         if (fs == STAGE) return final_at<GS, MAXPER, STAGE>(ws, g, c, rsel);
         return final_from<GS, MAXPER, STAGE + 1, NST>(ws, g, fs, c, rsel);
@@ -692,18 +718,18 @@ template <int NST> __device__ __forceinline__ int chain_index_below(uint32_t x) 
 }
 
 template <int GS, int MAXPER>
-__device__ __forceinline__ uint32_t select_lds(const Work<LdsSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel, int &nvalid) {
+__device__ __forceinline__ Pick select_lds(const Work<LdsSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel, int &nvalid) {
     constexpr int NST = nst_of(MAXPER * GS);
     const int fs = chain_index_below<NST>(c);                                 // the final stage: first chain value >= c
     materialise_from<GS, MAXPER, 0, NST>(ws, g, fs, nvalid);
     return final_from<GS, MAXPER, 0, NST>(ws, g, fs, c, rsel);
 }
 
-template <int GS, int MAXPER> __device__ __forceinline__ uint32_t select_any(const Work<LdsSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel, int &nvalid) {
+template <int GS, int MAXPER> __device__ __forceinline__ Pick select_any(const Work<LdsSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel, int &nvalid) {
     return select_lds<GS, MAXPER>(ws, g, c, rsel, nvalid);
 }
-template <int GS, int MAXPER> __device__ __forceinline__ uint32_t select_any(const Work<GlbSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel, int &nvalid) {
-    return select_in_order<GS, GlbSpace>(ws, g, c, rsel, nvalid);
+template <int GS, int MAXPER> __device__ __forceinline__ Pick select_any(const Work<GlbSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel, int &nvalid) {
+    return Pick{select_in_order<GS, GlbSpace>(ws, g, c, rsel, nvalid), c};
 }
 
 // Adjacency row of the vertex just added to the sample (local index size-1):
@@ -744,6 +770,7 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
         if (hcount + (uint32_t)__popcll(g.ballot(cand)) > ws.hlimit) return false;
         // probe: only `seen` and `slot` are carried round the loop; what happened is read off `seen` afterwards
         uint32_t seen = kKeyMask;                                 // a value no probe returns for a candidate
+        STAMP_SUB_BEGIN();
         if (cand) {
             for (uint32_t it = 0; it <= ws.hmask; ++it) {         // the table is never full
                 seen = atomicCAS(&ws.HK[slot], kEmpty, w | kFresh);
@@ -751,6 +778,7 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
                 slot = (slot + 1) & ws.hmask;
             }
         }
+        STAMP_SUB_END_OF(1, 6);
         const bool inserted = cand && seen == kEmpty;
         const bool found = cand && seen != kEmpty && (seen & kKeyMask) == w;
         in_s = found && (seen & kInS) != 0u;
@@ -920,23 +948,25 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
     STAMP_END(0);
     int64_t r0 = 0, r1 = 0;
     int2 e0 = make_int2(0, 0);
-    bool ok;
-    if constexpr (PAD) {
-        e0 = load_prow(P, gd.vbase + root_v, g.lane);
-        ok = (k > 1) ? scan_prow<SP, true, STG>(ws, g, P, root_v, root_vi, size, c, hcount, ecount, e0, sc)
-                     : scan_prow<SP, false, STG>(ws, g, P, root_v, root_vi, size, c, hcount, ecount, e0, sc);
-    } else {
-        r0 = g.uni(P.rowptr[gd.rbase + root_v]); r1 = g.uni(P.rowptr[gd.rbase + root_v + 1]);
-        ok = (k > 1) ? scan_row<GS, SP, true, STG>(ws, g, P, root_v, root_vi, size, c, hcount, ecount, r0, r1, sc)
-                     : scan_row<GS, SP, false, STG>(ws, g, P, root_v, root_vi, size, c, hcount, ecount, r0, r1, sc);
-    }
-    STAMP_END(1);
-    if (!ok) return false;
-    for (int step = 1; step < k; ++step) {
-        if (c == 0) break;                                                    // growth failed: partial row
-        const uint32_t rsel = g.uni(mod64_by(rng.next(), c));
+    uint32_t v = root_v;                                                      // the vertex whose row is scanned next (local index size-1)
+    if constexpr (PAD) e0 = load_prow(P, gd.vbase + v, g.lane);
+    else { r0 = g.uni(P.rowptr[gd.rbase + v]); r1 = g.uni(P.rowptr[gd.rbase + v + 1]); }
+    for (int step = 0;; ++step) {
+        bool ok;
+        if (step < k - 1) {                                                   // the last vertex adds no candidates
+            if constexpr (PAD) ok = scan_prow<SP, true, STG>(ws, g, P, v, root_vi, size, c, hcount, ecount, e0, sc);
+            else ok = scan_row<GS, SP, true, STG>(ws, g, P, v, root_vi, size, c, hcount, ecount, r0, r1, sc);
+        } else {
+            if constexpr (PAD) ok = scan_prow<SP, false, STG>(ws, g, P, v, root_vi, size, c, hcount, ecount, e0, sc);
+            else ok = scan_row<GS, SP, false, STG>(ws, g, P, v, root_vi, size, c, hcount, ecount, r0, r1, sc);
+        }
+        STAMP_END(1);
+        if (!ok) return false;
+        if (step >= k - 1 || c == 0) break;                                   // complete, or growth failed: partial row
+        const uint32_t rsel = g.uni(mod64_by<sizeof(typename SP::TW) == 4>(rng.next(), c));
         STAMP_END(4);
-        const uint32_t w = select_any<GS, MAXPER>(ws, g, c, rsel, nvalid);
+        const Pick pick = select_any<GS, MAXPER>(ws, g, c, rsel, nvalid);
+        const uint32_t w = pick.w;
         if constexpr (PAD) {
             e0 = load_prow(P, gd.vbase + w, g.lane);                  // the row itself: issued now, consumed after the candidate list has been updated
         } else {
@@ -945,18 +975,22 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
             r0 = g.uni(r0); r1 = g.uni(r1);
         }
         STAMP_END(2);
-        // move w from the candidates to the sample: drop it from D keeping the order of the others
-        uint32_t q = c;
-        for (uint32_t t0 = 0; t0 < c && q == c; t0 += 4 * GS) {        // 4 chunks per LDS round trip
-            uint32_t x[4];
+        // move w from the candidates to the sample: drop it from D keeping the order of the others.  The LDS tiers' final stage
+        // names its position; the global-memory tier searches D.
+        uint32_t q = pick.q;
+        if constexpr (sizeof(typename SP::TW) != 4) {
+            for (uint32_t t0 = 0; t0 < c && q == c; t0 += 4 * GS) {    // 4 chunks per round trip
+                uint32_t x[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const uint32_t t = t0 + u * GS + g.lane; x[u] = (t < c) ? ws.D[t] : kEmpty; }
+                for (int u = 0; u < 4; ++u) { const uint32_t t = t0 + u * GS + g.lane; x[u] = (t < c) ? ws.D[t] : kEmpty; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint64_t mk = g.ballot(x[u] == w);
-                if (mk && q == c) q = t0 + u * GS + (uint32_t)(__ffsll((long long)mk) - 1);
+                for (int u = 0; u < 4; ++u) {
+                    const uint64_t mk = g.ballot(x[u] == w);
+                    if (mk && q == c) q = t0 + u * GS + (uint32_t)(__ffsll((long long)mk) - 1);
+                }
             }
         }
+        STAMP_END(7);
         for (uint32_t t0 = q; t0 + 1 < c; t0 += 4 * GS) {
             uint32_t x[4];
 #pragma unroll
@@ -977,23 +1011,20 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
             nvalid = keep;
         }
         c -= 1;
-        if (g.lane == 0) {
-            uint32_t s = hash_slot(w, ws.hmask);
-            for (uint32_t it = 0; it <= ws.hmask && ws.HK[s] != w; ++it) s = (s + 1) & ws.hmask;
-            ws.HK[s] = w | kInS;      // now a member of the sample
-            SV[size] = w;
+        STAMP_END(8);
+        {   // w is now a member of the sample: flag its hash entry (the group probes GS consecutive slots per round trip)
+            uint32_t s = (hash_slot(w, ws.hmask) + (uint32_t)g.lane) & ws.hmask;
+            for (uint32_t it = 0; it <= ws.hmask; it += GS) {
+                const bool hit = ws.HK[s] == w;                       // a candidate's entry carries no flag
+                if (g.any(hit)) { if (hit) ws.HK[s] = w | kInS; break; }
+                s = (s + GS) & ws.hmask;
+            }
+            if (g.lane == 0) SV[size] = w;
         }
         size += 1;
+        v = w;
         SP::sync();
         STAMP_END(3);
-        if constexpr (PAD)
-            ok = (step < k - 1) ? scan_prow<SP, true, STG>(ws, g, P, w, root_vi, size, c, hcount, ecount, e0, sc)
-                                : scan_prow<SP, false, STG>(ws, g, P, w, root_vi, size, c, hcount, ecount, e0, sc);
-        else
-            ok = (step < k - 1) ? scan_row<GS, SP, true, STG>(ws, g, P, w, root_vi, size, c, hcount, ecount, r0, r1, sc)
-                                : scan_row<GS, SP, false, STG>(ws, g, P, w, root_vi, size, c, hcount, ecount, r0, r1, sc);
-        STAMP_END(1);
-        if (!ok) return false;
     }
     const uint32_t nedges = (size == (uint32_t)k) ? ecount : 0u;                // incomplete rows carry no edges (:219-223)
     // staged hits: fetch their edge columns now, the row's epilogue below runs while the gather is in flight
@@ -1022,7 +1053,7 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
 // LDS words of one group's workspace for a tier (all sub-arrays 16-byte aligned)
 template <int CAP> struct TierCfg {
     static constexpr int NSTAGE = nst_of(CAP);                                     // stages that are ever materialised
-    static constexpr int ORDW = (int)((ord_words_before(NSTAGE) + 3u) & ~3u);     // 104 / 492 / 1036 / 2144 words
+    static constexpr int ORDW = (int)(((ord_words_before(NSTAGE) + 1u) / 2u + 3u) & ~3u);   // 16-bit positions: 52 / 248 / 520 / 1072 words
     static constexpr int BCAP = CAP <= 64 ? 127 : (CAP <= 512 ? 541 : (CAP <= 1024 ? 1109 : 2357));   // smallest chain value >= CAP
     static constexpr int BCAP_A = (BCAP + 3) & ~3;
     static constexpr int HS = CAP <= 64 ? 128 : (CAP <= 512 ? 512 : (CAP <= 1024 ? 2048 : 4096));
@@ -1048,9 +1079,9 @@ __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP <= 64 ||
     uint32_t *base = lds + gib * Cfg::WORDS;
     Work<LdsSpace> ws;
     ws.D = base;
-    ws.ORD = ws.D + CAP;
+    ws.ORD = reinterpret_cast<uint16_t *>(ws.D + CAP);
     ws.AUX = nullptr;                      // the register-resident stages need no per-element scratch
-    ws.TBL = ws.ORD + Cfg::ORDW;
+    ws.TBL = ws.D + CAP + Cfg::ORDW;
     ws.HK = ws.TBL + Cfg::BCAP_A;
     uint32_t *SV = ws.HK + Cfg::HS;
     uint4 *EL = Cfg::ELW ? reinterpret_cast<uint4 *>(SV + UGS_KMAX) : nullptr;
@@ -1066,12 +1097,14 @@ __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP <= 64 ||
 #endif
     const int64_t total = a.in_list ? (int64_t)*a.in_count : a.row_count;
     const int64_t ngroups = (int64_t)gridDim.x * GROUPS;
-    if (a.work_next) {
-        // dynamic split in chunks of kWorkChunk consecutive items: one counter round trip per chunk (a single hot address
-        // answers in several microseconds), balance to within a chunk at the end of the launch
+    // Work distribution.  Dynamic (a.work_next, launches with many more walks than resident groups): chunks of UGS_WORK_CHUNK
+    // consecutive items, the first chunk by group index, every further one from a device counter (one round trip per chunk: a
+    // single hot address answers in several microseconds); a walk's cost varies, so a static split ends with the unluckiest wave.
+    // Two loops, two inlined copies of the walk: one shared loop measured 0.8 % slower on C5 (register allocation).
 #ifndef UGS_WORK_CHUNK
 #define UGS_WORK_CHUNK 4
 #endif
+    if (a.work_next) {
         constexpr int64_t kWorkChunk = UGS_WORK_CHUNK;
         int64_t it = ((int64_t)blockIdx.x * GROUPS + gib) * kWorkChunk;
         while (it < total) {
@@ -1404,14 +1437,19 @@ static hipError_t launch_lds(const UgsWalkArgs &a, int cus, int blocks_per_cu, h
     return hipGetLastError();
 }
 
+#ifndef UGS_BLOCKS_M
+#define UGS_BLOCKS_M 20
+#endif
 hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, hipStream_t s, UgsLaunchInfo *info) {
     if (cus <= 0) cus = 256;
     switch (tier) {
     case UGS_TIER_S: return launch_lds<8, 64, 256>(a, cus, 2, s, info, "ugs_walk_lds<8,64>");
     // one walk per wave: two walks per wave (GS 32) measured 26.4 ms vs 18.7 ms per 1M walks on C5 (two chunks per row)
-    case UGS_TIER_M: return launch_lds<64, 448, 64>(a, cus, 18, s, info, "ugs_walk_lds<64,448>");   // all the LDS admits
-    case UGS_TIER_X: return launch_lds<64, 1024, 64>(a, cus, 7, s, info, "ugs_walk_lds<64,1024>");   // 21.5 KB of LDS per walk: 7 fit
-    case UGS_TIER_L: return launch_lds<64, 2048, 64>(a, cus, 3, s, info, "ugs_walk_lds<64,2048>");   // 43 KB of LDS per walk: 3 fit
+    // resident one-wave blocks per CU: LDS is granted in 1280-byte granules (128 per CU) -- 7648 B = 6 granules -> 21 blocks, of
+    // which the register budget (96 VGPRs: 5 waves per SIMD) admits 20; 19.5 KB = 16 granules -> 8; 38.9 KB = 31 granules -> 4
+    case UGS_TIER_M: return launch_lds<64, 448, 64>(a, cus, UGS_BLOCKS_M, s, info, "ugs_walk_lds<64,448>");
+    case UGS_TIER_X: return launch_lds<64, 1024, 64>(a, cus, 8, s, info, "ugs_walk_lds<64,1024>");
+    case UGS_TIER_L: return launch_lds<64, 2048, 64>(a, cus, 4, s, info, "ugs_walk_lds<64,2048>");
     default: {
         int64_t grid = a.gws_words_per_group > 0 ? a.gws_groups : 0;
         if (grid < 1) return hipErrorInvalidValue;
