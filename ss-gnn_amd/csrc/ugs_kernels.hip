@@ -537,23 +537,6 @@ __device__ __forceinline__ void stage_mat_reg2(const Work<LdsSpace> &ws, const G
     LdsSpace::sync();
 }
 
-__device__ __forceinline__ Pick stage_final_reg2(const Work<LdsSpace> &ws, const Grp<64> &g, const uint16_t *OLD, uint32_t n_old,
-                                                 uint32_t L, uint32_t B, uint32_t M, uint32_t S, uint32_t rsel) {
-    const uint32_t t0 = (uint32_t)g.lane, t1 = t0 + 64u;
-    const bool valid1 = t1 < L;
-    uint32_t pos0 = t0, pos1 = t1;
-    if (t0 < n_old) pos0 = OLD[t0];
-    if (valid1 && t1 < n_old) pos1 = OLD[t1];
-    const uint32_t key0 = ws.D[pos0];
-    uint32_t key1 = 0u;
-    if (valid1) key1 = ws.D[pos1];
-    const Rank2 r = rank2_in_registers(g, valid1, mod_magic(key0, B, M, S), mod_magic(key1, B, M, S), S + 1u);
-    const bool h0 = r.r0 == rsel, h1 = valid1 && r.r1 == rsel;
-    const uint64_t hm = __ballot(h0 || h1);
-    const int src = hm ? (__ffsll((long long)hm) - 1) : 0;
-    return Pick{g.bcast(h0 ? key0 : key1, src), g.bcast(h0 ? pos0 : pos1, src)};
-}
-
 // The LAST stage only has to name the element at iteration position `rsel`, so nothing is ranked or materialised:
 // one atomicMin (first position of every bucket) and one atomicAdd (its size) on the same word, a scan of the sizes
 // over the bucket leaders to find the bucket that holds position rsel, and ballots among that bucket's few members.
@@ -673,21 +656,19 @@ __device__ __forceinline__ Pick final_at(const Work<LdsSpace> &ws, const Grp<GS>
 #else
 #define UGS_FINAL_CASE(LO, HI, CALL) if constexpr (pmin <= (HI) && pmax >= (LO)) { if (pmax <= (HI) || per <= (HI)) return CALL; }
 #endif
+    // Which variant serves how many elements per lane (measured on C5, VALU-bound at 20 waves/CU): up to 64 candidates the
+    // register-ranked final (78 VALU instructions against 59 + 7 LDS operations for the table variant: the shorter dependency
+    // chain wins); from 65 on the bucket-table variant with exactly ceil(c/64) elements per lane -- for 65..128 candidates it
+    // takes 93 VALU instructions where ranking two elements per lane in registers took 207 (7.16 -> 7.01 ms per 1M walks).
+#define UGS_FINAL_LDS(LO, HI, NJ) UGS_FINAL_CASE(LO, HI, (stage_final<GS, NJ>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
     if constexpr (GS == 64) {
         UGS_FINAL_CASE(1, 1, stage_final_reg(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel))
-        UGS_FINAL_CASE(2, 2, stage_final_reg2(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel))
-        UGS_FINAL_CASE(3, 3, (stage_final<GS, 3>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
+        UGS_FINAL_LDS(2, 2, 2) UGS_FINAL_LDS(3, 3, 3) UGS_FINAL_LDS(4, 4, 4) UGS_FINAL_LDS(5, 5, 5) UGS_FINAL_LDS(6, 6, 6) UGS_FINAL_LDS(7, 7, 7)
     } else {
-        UGS_FINAL_CASE(1, 1, (stage_final<GS, 1>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
-        UGS_FINAL_CASE(2, 3, (stage_final<GS, 3>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
+        UGS_FINAL_LDS(1, 1, 1) UGS_FINAL_LDS(2, 3, 3) UGS_FINAL_LDS(4, 5, 5) UGS_FINAL_LDS(6, 7, 7)
     }
-    UGS_FINAL_CASE(4, 5, (stage_final<GS, 5>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
-    UGS_FINAL_CASE(6, 7, (stage_final<GS, 7>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
-    UGS_FINAL_CASE(8, 9, (stage_final<GS, 9>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
-    UGS_FINAL_CASE(10, 11, (stage_final<GS, 11>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
-    UGS_FINAL_CASE(12, 13, (stage_final<GS, 13>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
-    UGS_FINAL_CASE(14, 17, (stage_final<GS, 17>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
-    UGS_FINAL_CASE(18, 1 << 20, (stage_final<GS, 33>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
+    UGS_FINAL_LDS(8, 9, 9) UGS_FINAL_LDS(10, 11, 11) UGS_FINAL_LDS(12, 13, 13) UGS_FINAL_LDS(14, 17, 17) UGS_FINAL_LDS(18, 1 << 20, 33)
+#undef UGS_FINAL_LDS
 #undef UGS_FINAL_CASE
     return Pick{0u, 0u};
 }
