@@ -19,7 +19,9 @@
 //                                    (CSR degree, absolute CSR position of the row's first entry), entries 1.. are the first
 //                                    2^s - 1 (w, rank(w)) pairs of the row; longer rows continue in adj[].  A walk step then needs
 //                                    ONE dependent memory round trip (the row, at an address computed from the vertex) instead
-//                                    of two (row pointer, then row), and no line is fetched for a row-pointer pair.
+//                                    of two (row pointer, then row), and no line is fetched for a row-pointer pair.  Only the lines
+//                                    a typical visited row fills are fetched with the header (prow_first entries); the block's
+//                                    remaining lines follow for the rows that reach into them.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -55,7 +57,7 @@ struct UgsPlanDev {
     int64_t num_graphs;
     const int2 *prow;        // padded rows (NULL until built; the 8-lane and global-memory tiers use rowptr + adj)
     int32_t prow_shift;      // log2(entries per padded row), 3..6
-    int32_t prow_pad;
+    int32_t prow_first;      // entries fetched before the degree is known (whole 128-byte lines); the rest of the block only if the row needs it
 };
 
 struct UgsWalkArgs {

@@ -773,6 +773,11 @@ int ensure_prow(ugs_plan *plan, hipStream_t s) {
     HIP_TRY(hipStreamSynchronize(s));          // once per plan: later calls may come on other streams
     plan->dev.prow = static_cast<const int2 *>(plan->prow.p);
     plan->dev.prow_shift = shift;
+    // entries fetched together with the header: whole 128-byte lines (16 entries) covering the typical visited row; a row that
+    // reaches further costs one more (dependent) load of the block's remaining lines
+    int first = (int)std::ceil((sb + 0.5 * std::sqrt(sb) + 1.0) / 16.0) * 16;
+    if (const char *e = std::getenv("UGS_PROW_FIRST")) { const int f = std::atoi(e); if (f >= 1) first = f; }
+    plan->dev.prow_first = std::max(1, std::min(first, 1 << shift));
     return UGS_OK;
 }
 

@@ -823,18 +823,21 @@ __device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, c
 // Lane 0 holds the header (degree, CSR position of the first entry), lanes 1.. the first entries; a longer row continues in adj[].
 __device__ __forceinline__ int2 load_prow(const UgsPlanDev &P, int64_t vrow, int lane) {
     int2 e = make_int2(0, 0);
-    if (lane < (1 << P.prow_shift)) e = P.prow[(vrow << P.prow_shift) + lane];
+    if (lane < P.prow_first) e = P.prow[(vrow << P.prow_shift) + lane];
     return e;
 }
 
 template <class SP, bool ADD, bool STG>
 __device__ __forceinline__ bool scan_prow(const Work<SP> &ws, const Grp<64> &g, const UgsPlanDev &P, uint32_t v,
                                           uint32_t root_vi, uint32_t size, uint32_t &c, uint32_t &hcount,
-                                          uint32_t &ecount, int2 e0, StageCtx &sc) {
+                                          uint32_t &ecount, int2 e0, int64_t vrow, StageCtx &sc) {
     const uint32_t deg = g.bcast((uint32_t)e0.x, 0);
     const int64_t start = (int64_t)g.bcast((uint32_t)e0.y, 0);
     const uint32_t inl = (1u << P.prow_shift) - 1u;                              // entries held by the block itself
     const uint32_t n0 = deg < inl ? deg : inl;
+    if (n0 >= (uint32_t)P.prow_first) {                                          // the row reaches into the lines not fetched yet
+        if (g.lane >= P.prow_first && g.lane <= (int)n0) e0 = P.prow[(vrow << P.prow_shift) + g.lane];
+    }
     if (n0 && !scan_chunk<64, SP, ADD, STG>(ws, g, v, root_vi, size, c, hcount, ecount, sc, (uint32_t)(g.lane - 1) < n0, e0, start + g.lane - 1)) return false;
     const int64_t r1 = start + deg;
     for (int64_t base = start + inl; base < r1; base += 64) {
@@ -935,10 +938,10 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
     for (int step = 0;; ++step) {
         bool ok;
         if (step < k - 1) {                                                   // the last vertex adds no candidates
-            if constexpr (PAD) ok = scan_prow<SP, true, STG>(ws, g, P, v, root_vi, size, c, hcount, ecount, e0, sc);
+            if constexpr (PAD) ok = scan_prow<SP, true, STG>(ws, g, P, v, root_vi, size, c, hcount, ecount, e0, gd.vbase + v, sc);
             else ok = scan_row<GS, SP, true, STG>(ws, g, P, v, root_vi, size, c, hcount, ecount, r0, r1, sc);
         } else {
-            if constexpr (PAD) ok = scan_prow<SP, false, STG>(ws, g, P, v, root_vi, size, c, hcount, ecount, e0, sc);
+            if constexpr (PAD) ok = scan_prow<SP, false, STG>(ws, g, P, v, root_vi, size, c, hcount, ecount, e0, gd.vbase + v, sc);
             else ok = scan_row<GS, SP, false, STG>(ws, g, P, v, root_vi, size, c, hcount, ecount, r0, r1, sc);
         }
         STAMP_END(1);
