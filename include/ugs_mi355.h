@@ -53,6 +53,13 @@ int ugs_device_count(int *count);
 /* Select the HIP device used by the calling thread's subsequent calls (default: current HIP device). */
 int ugs_set_device(int device);
 
+/* Stream of the calling thread's subsequent JOBS (ugs_sample_*, ugs_sample_batch_*, ugs_eps_*): `use` != 0 runs their kernels
+ * and copies on `stream` (a hipStream_t; NULL = the default stream) instead of the library's own non-blocking stream; `use` = 0
+ * restores the library's stream.  A caller that hands in DEVICE output buffers obtained from a stream-ordered allocator
+ * (torch.empty on torch's current stream) must run the job on that stream: a block the allocator just recycled may still be
+ * read by kernels queued there, and only stream order keeps the job's writes behind them.  The plan API takes its stream per call. */
+int ugs_set_stream(void *stream, int use);
+
 /* ---- preprocessing handles: replaces create_preproc / destroy_preproc / has_graphlets / get_preproc_info
  *      (reference src/preproc.cpp:262-314, pybind names src/extension.cpp:7-10) -------------------------------- */
 int ugs_create_preproc(const int64_t *edge_index, int64_t row_stride, int64_t num_cols, int64_t num_nodes, int k,
@@ -115,14 +122,16 @@ int ugs_plan_info(const ugs_plan *plan, int k, int64_t *num_graphs, int64_t *num
 int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int seed,
                   int64_t row_begin, int64_t row_count, void *stream, int64_t *d_nodes, int64_t *d_edge_ptr,
                   int64_t *total_edges_host);
-/* Fill phase: writes d_edge_index[2, ld] (row stride ld >= total edges) and d_edge_src[...] for the same rows. */
+/* Fill phase: writes d_edge_index[2, ld] and d_edge_src[ld] for the same rows.  ld is the row stride of d_edge_index AND the
+ * capacity (in edge entries) of both buffers: entries at positions >= ld are not written (a caller that sized the buffers from
+ * an estimate compares d_edge_ptr[row_count] with ld afterwards). */
 int ugs_plan_fill(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int64_t row_begin,
                   int64_t row_count, void *stream, const int64_t *d_nodes, const int64_t *d_edge_ptr,
                   int64_t *d_edge_index, int64_t ld, int64_t *d_edge_src);
 /* A whole step (seed upload, walk tiers, scan, fill) of a plan captured ONCE as a HIP graph and replayed with a new seed:
  * for batches of small graphs a step is a handful of launches for tens of microseconds of work, and the graph removes the
  * per-launch gaps.  The buffers are the caller's (d_edge_index[2, ld], d_edge_src[ld]: ld >= the largest total it expects;
- * a replay whose total exceeds ld must not be used -- compare d_edge_ptr[row_count] with ld).  No reference counterpart
+ * entries beyond ld are not written, and a replay whose total exceeds ld must not be used -- compare d_edge_ptr[row_count] with ld).  No reference counterpart
  * (the reference launches nothing); same results as ugs_plan_walk + ugs_plan_fill with that seed.  Launches of one graph
  * must be issued by one thread at a time and on one stream at a time (the outputs are the graph's buffers); up to 256 replays
  * may be in flight (ring of pinned seed slots). */

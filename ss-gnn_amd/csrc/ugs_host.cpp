@@ -262,8 +262,11 @@ int make_graph(const int64_t *src, const int64_t *dst, int64_t E, int64_t n, int
 // ---------------------------------------------------------------------------------------------------------------
 // handle registry (monotonically increasing int64 handles from 1)
 // ---------------------------------------------------------------------------------------------------------------
+// The process-wide containers below are heap objects that are never destroyed: at process exit no destructor of this library
+// runs (a Graph's destructor releases device plans into the scratch pool and calls the HIP runtime, neither of which may
+// still exist during static destruction).
 std::mutex g_reg_mu;
-std::unordered_map<int64_t, std::shared_ptr<Graph>> g_reg;
+std::unordered_map<int64_t, std::shared_ptr<Graph>> &g_reg = *new std::unordered_map<int64_t, std::shared_ptr<Graph>>();
 int64_t g_next_handle = 1;
 
 std::shared_ptr<Graph> lookup(int64_t h) {
@@ -337,8 +340,10 @@ uint64_t graph_key(const int64_t *u, const int64_t *v, int64_t cols, int64_t n) 
 // ---------------------------------------------------------------------------------------------------------------
 struct DeviceCtx { int id = -1; int cus = 256; hipStream_t stream = nullptr; };
 std::mutex g_dev_mu;
-std::map<int, DeviceCtx> g_devs;
+std::map<int, DeviceCtx> &g_devs = *new std::map<int, DeviceCtx>();
 thread_local int t_device = -1;
+thread_local hipStream_t t_job_stream = nullptr;    // ugs_set_stream: stream of the calling thread's jobs (NULL: the library's own)
+thread_local bool t_job_stream_set = false;
 
 int device_ctx(DeviceCtx &out) {
     int dev = t_device;
@@ -360,13 +365,14 @@ int device_ctx(DeviceCtx &out) {
         it = g_devs.emplace(dev, c).first;
     }
     out = it->second;
+    if (t_job_stream_set) out.stream = t_job_stream;
     return UGS_OK;
 }
 
 // grow-only device scratch pool (per process): avoids hipMalloc/hipFree on every call
 struct PoolBuf { void *p = nullptr; size_t bytes = 0; int dev = -1; };
 std::mutex g_pool_mu;
-std::vector<PoolBuf> g_pool_free;
+std::vector<PoolBuf> &g_pool_free = *new std::vector<PoolBuf>();
 int pool_get(size_t bytes, int dev, PoolBuf &out) {
     if (bytes < 256) bytes = 256;
     {
@@ -429,6 +435,11 @@ struct ugs_plan {
     // edges staged by the last walk (UgsWalkArgs::stage) and the call they belong to: a fill of exactly those rows into/from
     // the same nodes buffer expands them; any other fill reads the adjacency rows again
     PoolBuf stage, staged, ulist, work;   // work: 3 x u64 next-item counters (one per walk launch of a call)
+    // stream order between calls: a plan's scratch is reused by every call, so a call on another stream than the previous one
+    // first waits (on the device) for that call's last kernel
+    hipEvent_t last_ev = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool last_valid = false;
     PoolBuf prow;                         // padded rows (ugs_device.h), built on the device by the first walk in a one-walk-per-wave tier
     bool prow_pooled = false, prow_failed = false;
     bool stg_valid = false;
@@ -622,6 +633,7 @@ void destroy_plan(ugs_plan *p) {
     if (!p) return;
     if (p->device >= 0 && hipSetDevice(p->device) == hipSuccess) (void)hipDeviceSynchronize();   // kernels may still read the plan
     ev_clear(p);
+    if (p->last_ev) (void)hipEventDestroy(p->last_ev);
     if (p->blob_buf.p) pool_put(p->blob_buf); else if (p->blob) (void)hipFree(p->blob);
     pool_put(p->counts); pool_put(p->ovf1); pool_put(p->ovf2); pool_put(p->ovfcnt); pool_put(p->scantmp);
     pool_put(p->stage); pool_put(p->staged); pool_put(p->ulist); pool_put(p->work);
@@ -635,7 +647,7 @@ namespace {
 
 // plan cache of batches (small LRU; a hit skips assembly + upload)
 std::mutex g_pc_mu;
-std::list<ugs_plan *> g_plan_cache;     // front = most recent
+std::list<ugs_plan *> &g_plan_cache = *new std::list<ugs_plan *>();     // front = most recent
 size_t g_plan_cache_cap = 64;
 size_t g_plan_cache_bytes_cap = (size_t)8 << 30;
 
@@ -781,10 +793,30 @@ int ensure_prow(ugs_plan *plan, hipStream_t s) {
     return UGS_OK;
 }
 
-int ensure(PoolBuf &b, size_t bytes, int dev) {
+// plan scratch, grown on demand.  The old buffer goes back to the process-wide pool, where any stream may pick it up: the
+// plan's last call has to be over first (rare: sizes settle after the first calls).
+int ensure(PoolBuf &b, size_t bytes, int dev, ugs_plan *plan) {
     if (b.p && b.bytes >= bytes) return UGS_OK;
+    if (b.p && plan && plan->last_valid) HIP_TRY(hipStreamSynchronize(plan->last_stream));
     pool_put(b);
     return pool_get(bytes, dev, b);
+}
+
+bool capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+// call with plan->mu held, before the first / after the last kernel of a call on stream s
+int plan_enter(ugs_plan *plan, hipStream_t s) {
+    if (plan->last_valid && plan->last_stream != s && !capturing(s)) HIP_TRY(hipStreamWaitEvent(s, plan->last_ev, 0));
+    return UGS_OK;
+}
+int plan_leave(ugs_plan *plan, hipStream_t s) {
+    if (capturing(s)) return UGS_OK;
+    if (!plan->last_ev) HIP_TRY(hipEventCreateWithFlags(&plan->last_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(plan->last_ev, s));
+    plan->last_stream = s; plan->last_valid = true;
+    return UGS_OK;
 }
 
 }  // namespace
@@ -811,6 +843,12 @@ int ugs_set_device(int device) {
     if (device < 0 || device >= c) return fail(UGS_E_BAD_ARG, "device index out of range");
     t_device = device;
     HIP_TRY(hipSetDevice(device));
+    return UGS_OK;
+}
+
+int ugs_set_stream(void *stream, int use) {
+    t_job_stream = static_cast<hipStream_t>(stream);
+    t_job_stream_set = use != 0;
     return UGS_OK;
 }
 
@@ -1004,28 +1042,29 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
     }
     const TierChoice tc = choose_tier(plan, k);
     std::lock_guard<std::mutex> lk(plan->mu);
-    if (int rc = ensure(plan->counts, (size_t)row_count * sizeof(uint32_t), plan->device)) return rc;
-    if (int rc = ensure(plan->scantmp, (size_t)ugs_scan_tmp_words(row_count) * sizeof(int64_t), plan->device)) return rc;
-    if (int rc = ensure(plan->ovfcnt, 4 * sizeof(uint32_t), plan->device)) return rc;
+    if (int rc = plan_enter(plan, s)) return rc;
+    if (int rc = ensure(plan->counts, (size_t)row_count * sizeof(uint32_t), plan->device, plan)) return rc;
+    if (int rc = ensure(plan->scantmp, (size_t)ugs_scan_tmp_words(row_count) * sizeof(int64_t), plan->device, plan)) return rc;
+    if (int rc = ensure(plan->ovfcnt, 4 * sizeof(uint32_t), plan->device, plan)) return rc;
     const bool may_overflow = tc.second >= 0 || tc.third_G;
     if (may_overflow) {
-        if (int rc = ensure(plan->ovf1, (size_t)row_count * sizeof(int64_t), plan->device)) return rc;
-        if (int rc = ensure(plan->ovf2, (size_t)row_count * sizeof(int64_t), plan->device)) return rc;
+        if (int rc = ensure(plan->ovf1, (size_t)row_count * sizeof(int64_t), plan->device, plan)) return rc;
+        if (int rc = ensure(plan->ovf2, (size_t)row_count * sizeof(int64_t), plan->device, plan)) return rc;
     }
     // edge staging by the walk (tiers with one walk per wave): 512 bytes of scratch per row, bounded
     const int64_t stage_max = [] { const char *e = std::getenv("UGS_STAGE_MAX_MB"); return (int64_t)(e ? std::atoll(e) : 4096) << 20; }();   // read per call (tests toggle it)
     const bool stg = tc.first != UGS_TIER_S && row_count * (int64_t)(UGS_STAGE_ITEMS * sizeof(uint2)) <= stage_max;
     plan->stg_valid = false;
     if (stg) {
-        if (int rc = ensure(plan->stage, (size_t)row_count * UGS_STAGE_ITEMS * sizeof(uint2), plan->device)) return rc;
-        if (int rc = ensure(plan->staged, (size_t)row_count, plan->device)) return rc;
-        if (int rc = ensure(plan->ulist, (size_t)row_count * sizeof(int64_t), plan->device)) return rc;
+        if (int rc = ensure(plan->stage, (size_t)row_count * UGS_STAGE_ITEMS * sizeof(uint2), plan->device, plan)) return rc;
+        if (int rc = ensure(plan->staged, (size_t)row_count, plan->device, plan)) return rc;
+        if (int rc = ensure(plan->ulist, (size_t)row_count * sizeof(int64_t), plan->device, plan)) return rc;
     }
     if (may_overflow || stg) HIP_TRY(hipMemsetAsync(plan->ovfcnt.p, 0, 4 * sizeof(uint32_t), s));   // nothing else reads the counters
     // dynamic work distribution pays when a launch has many more walks than resident groups (its counter costs one memset)
     const bool dyn = row_count > (int64_t)plan->cus * (tc.first == UGS_TIER_S ? 1024 : 64) && std::getenv("UGS_STATIC_SPLIT") == nullptr;
     if (dyn) {
-        if (int rc = ensure(plan->work, 4 * sizeof(unsigned long long), plan->device)) return rc;
+        if (int rc = ensure(plan->work, 4 * sizeof(unsigned long long), plan->device, plan)) return rc;
         HIP_TRY(hipMemsetAsync(plan->work.p, 0, 4 * sizeof(unsigned long long), s));
     }
     if ((tc.first != UGS_TIER_S && tc.first != UGS_TIER_G) || tc.second >= 0)
@@ -1091,6 +1130,7 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
     }
     HIP_TRY(ugs_launch_scan(static_cast<const uint32_t *>(plan->counts.p), row_count, d_edge_ptr, static_cast<int64_t *>(plan->scantmp.p), s));
     HIP_TRY(ev_end(plan, s));
+    if (int rc = plan_leave(plan, s)) return rc;
     if (total_edges_host) {
         uint32_t h[4] = {0, 0, 0, 0};
         int64_t tot = 0;
@@ -1128,10 +1168,11 @@ int ugs_plan_fill(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
         a.stage = static_cast<const uint2 *>(plan->stage.p); a.staged = static_cast<const uint8_t *>(plan->staged.p);
         a.ulist = static_cast<const int64_t *>(plan->ulist.p); a.ucount = static_cast<const uint32_t *>(plan->ovfcnt.p) + 3;
     }
+    if (int rc = plan_enter(plan, static_cast<hipStream_t>(stream))) return rc;
     HIP_TRY(ev_begin(plan, 2, static_cast<hipStream_t>(stream)));
     HIP_TRY(ugs_launch_fill(a, tc.first != UGS_TIER_S, plan->cus, static_cast<hipStream_t>(stream), &plan->last_fill));
     HIP_TRY(ev_end(plan, static_cast<hipStream_t>(stream)));
-    return UGS_OK;
+    return plan_leave(plan, static_cast<hipStream_t>(stream));
 }
 
 // ---- a step captured as a HIP graph (include/ugs_mi355.h) -----------------------------------------------------------------

@@ -1320,8 +1320,8 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
 #pragma unroll
                     for (int t = 7; t >= 0; --t) l = (sv[t] == wv[u]) ? t : l;
                     const uint64_t mk = g.ballot(l >= 0);
-                    if (l >= 0) {
-                        const int64_t pos = w_off + __popcll(mk & g.lt_mask());
+                    const int64_t pos = w_off + __popcll(mk & g.lt_mask());
+                    if (l >= 0 && pos < a.ld) {                           // ld is also the capacity of the caller's edge buffers
                         const int j = jj[u];
                         int64_t uf, vf;
                         if (a.mode == 0) { uf = j; vf = l; }
@@ -1358,8 +1358,8 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
                 int l = -1;
                 if (wv[u] != kEmpty) { for (int t = 0; t < k; ++t) if (SV[t] == wv[u]) { l = t; break; } }
                 const uint64_t mk = g.ballot(l >= 0);
-                if (l >= 0) {
-                    const int64_t pos = w_off + __popcll(mk & g.lt_mask());
+                const int64_t pos = w_off + __popcll(mk & g.lt_mask());
+                if (l >= 0 && pos < a.ld) {
                     const int j = jj[u];
                     int64_t uf, vf;
                     if (a.mode == 0) { uf = j; vf = l; }
@@ -1485,7 +1485,7 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill_staged(UgsFillArgs a) {
             const int64_t row = a.row_begin + row_rel;
             i = (P.num_graphs == 1) ? row : row % a.m;
         }
-        for (int t = lane; t < n && t < UGS_STAGE_ITEMS; t += GS) {
+        for (int t = lane; t < n && t < UGS_STAGE_ITEMS && e0 + t < a.ld; t += GS) {   // ld is also the buffers' capacity
             const uint2 x = items[t];
             const int j = (int)(x.y & 0xFFu), l = (int)(x.y >> 8);
             int64_t uf, vf;

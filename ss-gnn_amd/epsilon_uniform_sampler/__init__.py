@@ -35,10 +35,14 @@ def sample_batch(edge_index, ptr, m_per_graph, k, mode="sample", seed=42, epsilo
     G = pt.numel() - 1
     m, k = int(m_per_graph), int(k)
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-    if in_dev.type == "cuda":
-        check(lib.ugs_set_device(in_dev.index if in_dev.index is not None else torch.cuda.current_device()))
-    elif torch.cuda.is_available():
-        check(lib.ugs_set_device(torch.cuda.current_device()))
+    if in_dev.type == "cuda":     # device in, device out: the job runs on torch's current stream of that device (see ugs_set_stream)
+        idx = in_dev.index if in_dev.index is not None else torch.cuda.current_device()
+        check(lib.ugs_set_device(idx))
+        check(lib.ugs_set_stream(torch.cuda.current_stream(idx).cuda_stream, 1))
+    else:
+        if torch.cuda.is_available():
+            check(lib.ugs_set_device(torch.cuda.current_device()))
+        check(lib.ugs_set_stream(None, 0))
     job, total = vp(), C.c_int64()
     check(lib.ugs_eps_sample_batch_begin(ei.data_ptr(), ei.stride(0) if ei.size(1) else 0, ei.size(1), pt.data_ptr(), G, m, k,
                                          0 if mode == "sample" else 1, C.c_uint64(seed), C.c_double(float(epsilon)),

@@ -73,12 +73,21 @@ def device_count():
     return n.value
 
 
-def _select_device(device):
+def _select_device(device, jobs=False):
+    """Device of the calling thread's next library calls.  For a job (`jobs`) that returns DEVICE tensors, the job also runs on
+    torch's current stream of that device: the outputs come from torch's stream-ordered allocator, and only stream order keeps
+    the job's writes behind kernels that may still read a recycled block."""
     if device is not None:
         idx = torch.device(device).index
-        check(lib.ugs_set_device(idx if idx is not None else torch.cuda.current_device()))
-    elif torch.cuda.is_available():
-        check(lib.ugs_set_device(torch.cuda.current_device()))
+        idx = idx if idx is not None else torch.cuda.current_device()
+        check(lib.ugs_set_device(idx))
+        if jobs:
+            check(lib.ugs_set_stream(torch.cuda.current_stream(idx).cuda_stream, 1))
+    else:
+        if torch.cuda.is_available():
+            check(lib.ugs_set_device(torch.cuda.current_device()))
+        if jobs:
+            check(lib.ugs_set_stream(None, 0))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -136,7 +145,7 @@ def sample(handle, m_per_graph, k, edge_mode="local", base_offset=0, seed=42, *,
     m, k, seed = _as_c_int(m_per_graph, "m_per_graph"), _as_c_int(k, "k"), _as_c_int(seed, "seed")
     if edge_mode not in _EDGE_MODES:
         raise RuntimeError("edge_mode must be one of: 'local', 'flat', 'global'")
-    _select_device(device)
+    _select_device(device, jobs=True)
     job, total = vp(), C.c_int64()
     check(lib.ugs_sample_begin(int(handle), m, k, _EDGE_MODES[edge_mode], int(base_offset), seed, C.byref(job), C.byref(total)))
     try:
@@ -168,7 +177,7 @@ def sample_batch(edge_index, ptr, m_per_graph, k, mode="sample", seed=42, *, dev
     keep, p, stride, e = _edge_index_view(edge_index)
     ptr_c = ptr.contiguous()
     G = ptr_c.numel() - 1
-    _select_device(device)
+    _select_device(device, jobs=True)
     job, total = vp(), C.c_int64()
     check(lib.ugs_sample_batch_begin(p, stride, e, ptr_c.data_ptr(), G, m, k, _BATCH_MODES[mode], seed, C.byref(job), C.byref(total)))
     try:
@@ -195,7 +204,10 @@ class GraphStep:
         dev = torch.device("cuda", torch.cuda.current_device())
         k = plan.k
         if edge_capacity is None:
-            edge_capacity = max(1, row_count * k * (k - 1))          # every ordered pair of every row (simple graphs)
+            # every ordered pair of every row, twice: PyG batches store both directions of an edge and the sampler symmetrises
+            # every column (reference src/preproc.cpp:32-86), so each pair shows up two times.  Repeated columns can exceed
+            # this; the fill kernels never write past the capacity and result() reports the overflow.
+            edge_capacity = max(1, 2 * row_count * k * (k - 1))
         self.plan, self.rows, self.capacity = plan, row_count, int(edge_capacity)
         self.nodes = torch.empty((row_count, k), dtype=torch.int64, device=dev)
         self.edge_ptr = torch.empty((row_count + 1,), dtype=torch.int64, device=dev)

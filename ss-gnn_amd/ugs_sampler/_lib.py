@@ -22,6 +22,7 @@ def _load():
     sig = {
         "ugs_device_count": [C.POINTER(C.c_int)],
         "ugs_set_device": [C.c_int],
+        "ugs_set_stream": [vp, C.c_int],
         "ugs_create_preproc": [vp, C.c_int64, C.c_int64, C.c_int64, C.c_int, i64p],
         "ugs_destroy_preproc": [C.c_int64],
         "ugs_has_graphlets": [C.c_int64, C.POINTER(C.c_int)],

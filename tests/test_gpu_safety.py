@@ -1,0 +1,133 @@
+"""GPU: memory- and stream-safety of the boundary (regressions for review findings, no reference counterpart).
+
+  * fill kernels never write past the capacity the caller states (`ld`), whatever the batch's multiplicity;
+  * jobs that return device tensors run on torch's current stream (ugs_set_stream), so they are ordered with the consumer;
+  * one plan used from two streams: the second call waits for the first one's kernels (the plan's scratch is shared).
+Everything is checked against the CPU oracle (bit-exact, integer outputs)."""
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180)]
+
+
+def _clique_batch(n, G, copies=1):
+    """G cliques of n vertices, both directions of every edge stored (PyG style), every column `copies` times."""
+    cols, ptr = [], [0]
+    for g in range(G):
+        off = g * n
+        e = [(off + u, off + v) for u in range(n) for v in range(n) if u != v]
+        cols += e * copies
+        ptr.append(off + n)
+    return np.array(cols, dtype=np.int64).T.reshape(2, -1).copy(), np.array(ptr, dtype=np.int64)
+
+
+def test_captured_step_never_writes_past_its_capacity():
+    import torch
+    import oracle
+    import ugs_sampler
+    k, m = 4, 16
+    # (a) both directions stored: every ordered pair of a row shows up twice -> 2*k*(k-1) entries per row, the default capacity
+    ei, ptr = _clique_batch(6, 4)
+    plan = ugs_sampler.Plan.from_batch(torch.from_numpy(ei), torch.from_numpy(ptr), k)
+    rows = 4 * m
+    step = plan.graph_step(m, "sample")
+    assert step.capacity == 2 * rows * k * (k - 1)
+    step.launch(7)
+    got = [t.cpu().numpy() for t in step.result()]
+    want = oracle.sample_batch(ei, ptr, m, k, "sample", 7)
+    assert int(want[2][-1]) == step.capacity                                  # the bound is tight for cliques
+    for a, b in zip(got, (want[0], want[1], want[2], want[4])):
+        assert np.array_equal(a, b)
+    step.close()
+    # (b) repeated columns exceed any k-bound: a too small capacity must leave everything behind it untouched and be reported
+    ei3, ptr3 = _clique_batch(6, 4, copies=3)
+    plan3 = ugs_sampler.Plan.from_batch(torch.from_numpy(ei3), torch.from_numpy(ptr3), k)
+    want3 = oracle.sample_batch(ei3, ptr3, m, k, "sample", 7)
+    total = int(want3[2][-1])
+    cap = total // 2
+    dev = torch.device("cuda", torch.cuda.current_device())
+    CAN = -7777
+    big_idx = torch.full((2, cap + 4096), CAN, dtype=torch.int64, device=dev)
+    big_src = torch.full((cap + 4096,), CAN, dtype=torch.int64, device=dev)
+    nodes, eptr, tot = plan3.walk(m, "sample", 7)
+    assert tot == total
+    # edge_index [2, cap] as a strided view of a wider canary buffer; edge_src [cap] likewise
+    from ugs_sampler._lib import check, lib
+    check(lib.ugs_plan_fill(plan3._h, m, k, 0, 0, 0, rows, torch.cuda.current_stream().cuda_stream, nodes.data_ptr(), eptr.data_ptr(),
+                            big_idx.data_ptr(), cap, big_src.data_ptr()))
+    torch.cuda.synchronize()
+    flat = big_idx.reshape(-1).cpu().numpy()
+    assert np.array_equal(flat[:cap], want3[1][0, :cap]) and np.array_equal(flat[cap:2 * cap], want3[1][1, :cap])
+    assert (flat[2 * cap:] == CAN).all(), "fill wrote past the stated capacity of edge_index"
+    src = big_src.cpu().numpy()
+    assert np.array_equal(src[:cap], want3[4][:cap]) and (src[cap:] == CAN).all(), "fill wrote past the stated capacity of edge_src"
+    step3 = plan3.graph_step(m, "sample", edge_capacity=cap)
+    step3.launch(7)
+    with pytest.raises(RuntimeError, match="edge capacity"):
+        step3.result()
+    step3.close()
+
+
+def test_device_outputs_are_ordered_with_torchs_current_stream():
+    import torch
+    import oracle
+    import ugs_sampler
+    import ugs_workloads as wl
+    ei, ptr = wl.tu_batch(39, 73, 8)
+    ei_t, ptr_t = torch.from_numpy(ei), torch.from_numpy(ptr)
+    want = oracle.sample_batch(ei, ptr, 64, 6, "sample", 42)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    side = torch.cuda.Stream(device=dev)
+    x = torch.ones((4096, 4096), device=dev)
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            # a long-running reader of freshly freed blocks is queued on `side`; the job must queue behind it on the same stream
+            junk = [torch.empty((want[0].shape[0], 6), dtype=torch.int64, device=dev) for _ in range(4)]
+            y = x @ x
+            for j in junk:
+                j.fill_(-1)
+            del junk
+            got = ugs_sampler.sample_batch(ei_t, ptr_t, 64, 6, mode="sample", seed=42, device=dev)
+            chk = [g.clone() for g in got]                   # consumer on the same stream: must see the job's output
+        side.synchronize()
+        for a, b in zip(chk, want):
+            assert np.array_equal(a.cpu().numpy(), b)
+        del y
+    # host outputs afterwards use the library's own stream again
+    got = ugs_sampler.sample_batch(ei_t, ptr_t, 64, 6, mode="sample", seed=42)
+    for a, b in zip(got, want):
+        assert np.array_equal(a.numpy(), b)
+
+
+def test_one_plan_on_two_streams():
+    import torch
+    import oracle
+    import ugs_sampler
+    import ugs_workloads as wl
+    ei, ptr = wl.er_graph(20000, 400000, 3)
+    ei_t, ptr_t = torch.from_numpy(ei), torch.from_numpy(ptr)
+    k, m = 6, 30000
+    plan = ugs_sampler.Plan.from_batch(ei_t, ptr_t, k)
+    P = oracle.Preproc(ei, 20000, k)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    outs = {}
+    for rep in range(3):
+        for seed, st in ((11 + rep, s1), (501 + rep, s2)):       # back to back, no host synchronisation in between
+            with torch.cuda.stream(st):
+                nodes, eptr, _ = plan.walk(m, "sample", seed, sync=False)
+                outs[seed] = (nodes, eptr)
+    torch.cuda.synchronize()
+    for seed, (nodes, eptr) in outs.items():
+        w = P.sample(m, k, "local", 0, seed)
+        assert np.array_equal(nodes.cpu().numpy(), w[0]) and np.array_equal(eptr.cpu().numpy(), w[2]), f"seed {seed}"
+    # a sample_batch job (library / torch stream) right after an asynchronous plan call on another stream
+    with torch.cuda.stream(s1):
+        nodes, eptr, _ = plan.walk(m, "sample", 77, sync=False)
+    got = ugs_sampler.sample_batch(ei_t, ptr_t, 2000, k, mode="sample", seed=5)
+    torch.cuda.synchronize()
+    w = P.sample(m, k, "local", 0, 77)
+    assert np.array_equal(nodes.cpu().numpy(), w[0]) and np.array_equal(eptr.cpu().numpy(), w[2])
+    w5 = oracle.sample_batch(ei, ptr, 2000, k, "sample", 5)
+    for a, b in zip(got, w5):
+        assert np.array_equal(a.numpy(), b)
