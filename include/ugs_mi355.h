@@ -146,6 +146,25 @@ int ugs_plan_graph_destroy(ugs_graph *graph);
 int ugs_plan_last_launch(const ugs_plan *plan, char *name_buf, int name_buf_len, int *grid, int *block,
                          int *lds_bytes, int64_t *overflow_rows);
 
+/* ---- collation of a sharded batch (multi-GPU: SURVEY.md section 8(e); the reference is single-process and has no counterpart).
+ *      Rank r samples the contiguous row range [row_off[r], row_off[r+1]) of the G*m rows; the finished batch is collated on
+ *      the rank that feeds the trainer by ONE fixed-size message per rank (any transport: RCCL gather / all-gather of bytes).
+ *      Wire format of a message (little endian, every section 16-byte aligned; ugs_collate_layout gives the offsets):
+ *        header    int64 rows, int64 edge entries of this rank
+ *        nodes     [rows_cap, k]  int32 | int64                     (int32 when every node id fits)
+ *        edge_ptr  [rows_cap + 1] uint32, rank-local (starts at 0)
+ *        edge_index [2, edge_cap] uint8 | int32 | int64              (uint8: mode "sample", local ids < k)
+ *        edge_src  [edge_cap]     int32 | int64
+ *      rows_cap / edge_cap are the job's fixed capacities (>= every rank's rows / edge entries), so message size does not depend
+ *      on a step's outcome and no host round trip is needed per step.
+ *      ugs_collate_unpack turns `world` messages (contiguous, d_msgs[world][msg_bytes]) into the batch's int64 tensors on the
+ *      device: offsets are taken from the headers ON the device, entries at positions >= ld are not written. */
+int ugs_collate_layout(int k, int node_bytes, int eidx_bytes, int esrc_bytes, int64_t rows_cap, int64_t edge_cap,
+                       int64_t *section_off4, int64_t *msg_bytes);
+int ugs_collate_unpack(const void *d_msgs, int world, const int64_t *row_off /* host, world+1 */, int k, int node_bytes,
+                       int eidx_bytes, int esrc_bytes, int64_t rows_cap, int64_t edge_cap, int64_t *d_nodes,
+                       int64_t *d_edge_index, int64_t ld, int64_t *d_edge_ptr, int64_t *d_edge_src, void *stream);
+
 /* ---- epsilon_uniform_sampler.sample_batch(edge_index, ptr, m_per_graph, k, mode, seed, epsilon): replaces the reference's
  *      src/samplers/epsilon_uniform_sampler/src/epsilon_uniform_sampler.cpp:122-377.
  *      Random frontier growth (:18-87) with acceptance min(1, eps/(w+eps)) (:238), at most max(10, 10/eps) attempts per

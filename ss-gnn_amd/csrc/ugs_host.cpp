@@ -1264,6 +1264,36 @@ int ugs_plan_graph_launch(ugs_graph *g, int seed, void *stream) {
     return UGS_OK;
 }
 
+// ---- collation of a sharded batch (multi-GPU path; include/ugs_mi355.h: wire format) -------------------------------------------
+int ugs_collate_layout(int k, int node_bytes, int eidx_bytes, int esrc_bytes, int64_t rows_cap, int64_t edge_cap, int64_t *section_off4,
+                       int64_t *msg_bytes) {
+    if (k < 1 || rows_cap < 0 || edge_cap < 0 || !section_off4 || !msg_bytes) return fail(UGS_E_BAD_ARG, "bad arguments to collate_layout");
+    if ((node_bytes != 4 && node_bytes != 8) || (eidx_bytes != 1 && eidx_bytes != 4 && eidx_bytes != 8) || (esrc_bytes != 4 && esrc_bytes != 8))
+        return fail(UGS_E_BAD_ARG, "wire widths: nodes 4|8, edge_index 1|4|8, edge_src 4|8 bytes");
+    auto up = [](int64_t x) { return (x + 15) & ~(int64_t)15; };
+    int64_t off = 16;                                            // header: rows, edge entries (2 x int64)
+    section_off4[0] = off; off = up(off + rows_cap * k * node_bytes);
+    section_off4[1] = off; off = up(off + (rows_cap + 1) * 4);
+    section_off4[2] = off; off = up(off + 2 * edge_cap * eidx_bytes);
+    section_off4[3] = off; off = up(off + edge_cap * esrc_bytes);
+    *msg_bytes = off;
+    return UGS_OK;
+}
+
+int ugs_collate_unpack(const void *d_msgs, int world, const int64_t *row_off, int k, int node_bytes, int eidx_bytes, int esrc_bytes,
+                       int64_t rows_cap, int64_t edge_cap, int64_t *d_nodes, int64_t *d_edge_index, int64_t ld, int64_t *d_edge_ptr,
+                       int64_t *d_edge_src, void *stream) {
+    if (!d_msgs || !row_off || world < 1 || world > UGS_COLLATE_MAX_WORLD) return fail(UGS_E_BAD_ARG, "collate: 1 <= world <= 64 messages expected");
+    if (!d_nodes || !d_edge_ptr || (edge_cap > 0 && (!d_edge_index || !d_edge_src))) return fail(UGS_E_BAD_ARG, "null output pointer");
+    int64_t so[4], mb = 0;
+    if (int rc = ugs_collate_layout(k, node_bytes, eidx_bytes, esrc_bytes, rows_cap, edge_cap, so, &mb)) return rc;
+    for (int r = 0; r < world; ++r)
+        if (row_off[r + 1] < row_off[r] || row_off[r + 1] - row_off[r] > rows_cap) return fail(UGS_E_BAD_ARG, "collate: a rank's row range exceeds rows_cap");
+    HIP_TRY(ugs_launch_collate_unpack(d_msgs, world, mb, row_off, k, node_bytes, eidx_bytes, esrc_bytes, rows_cap, edge_cap, so, d_nodes,
+                                      d_edge_index, ld, d_edge_ptr, d_edge_src, static_cast<hipStream_t>(stream)));
+    return UGS_OK;
+}
+
 int ugs_plan_set_timing(ugs_plan *plan, int on) {
     if (!plan) return fail(UGS_E_BAD_ARG, "plan is null");
     std::lock_guard<std::mutex> lk(plan->mu);

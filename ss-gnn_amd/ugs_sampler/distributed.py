@@ -4,10 +4,21 @@ The path shards without any data-path collective: result row b = g*m + i depends
 (reference src/sampler.cpp:158-176: one RNG per sample, no shared state), so every rank samples a disjoint contiguous
 range of the G*m rows against its own HBM-resident copy of the plan.  The only exchange step is the collation of the
 finished batch on the rank that feeds the trainer (BASELINE.json north_star: "RCCL gather over xGMI only to collate the
-final batch").  xGMI is point-to-point and per-link bound, so the payload is narrowed before it travels: node ids and
-edge_src as int32 when they fit, per-row edge counts instead of offsets, local edge ids (mode "sample") as uint8 --
-about 3.4x fewer bytes than the int64 tensors -- and everything of a rank goes in ONE message.
+final batch").
+
+`Collator` is that step.  It is set up ONCE per job with fixed capacities, so a steady-state step needs no host round trip:
+  * every rank packs its rows into ONE fixed-size message (wire format: include/ugs_mi355.h, ugs_collate_layout).  xGMI is
+    point-to-point and per-link bound, so the payload is narrowed before it travels -- node ids and edge_src as int32 when
+    they fit, rank-local uint32 edge offsets, local edge ids (mode "sample") as uint8: about 3.4x fewer bytes than the int64
+    tensors; the conversion writes straight into the message (no padded staging copies);
+  * one gather (or all-gather) of those messages;
+  * the destination turns the `world` messages into the batch's int64 tensors in one pass, with the edge offsets of the ranks
+    computed ON the device from the message headers: a HIP kernel pair on the GPU (ugs_collate_unpack), torch index
+    operations with the same result on the CPU (gloo tests).
+Outputs keep their capacity: edge_index [2, cap] / edge_src [cap] are valid up to edge_ptr[-1], which stays on the device.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -30,81 +41,157 @@ def _wire_dtypes(k, mode, node_id_bound, edge_id_bound, col_bound):
     return nd, ed, sd
 
 
-def _pack(parts):
-    """concatenate tensors of mixed dtypes into one uint8 buffer (each part padded to 16 bytes)."""
-    chunks, layout, off = [], [], 0
-    for t in parts:
-        b = t.contiguous().view(torch.uint8).reshape(-1)
-        pad = (-b.numel()) % 16
-        if pad:
-            b = torch.cat([b, torch.zeros(pad, dtype=torch.uint8, device=b.device)])
-        layout.append((off, t.numel(), t.dtype, tuple(t.shape)))
-        off += b.numel()
-        chunks.append(b)
-    return torch.cat(chunks) if chunks else torch.zeros(0, dtype=torch.uint8), layout, off
+def _layout(k, nb, eb, sb, rows_cap, edge_cap):
+    """(section offsets [nodes, edge_ptr, edge_index, edge_src], message bytes) of the wire format -- asked from the library, so
+    that the Python packer and the HIP unpacker cannot disagree."""
+    from ._lib import check, lib
+    so, mb = (C.c_int64 * 4)(), C.c_int64()
+    check(lib.ugs_collate_layout(k, nb, eb, sb, int(rows_cap), int(edge_cap), so, C.byref(mb)))
+    return list(so), mb.value
 
 
-def _unpack(buf, layout):
-    out = []
-    for off, numel, dtype, shape in layout:
-        nbytes = numel * torch.empty((), dtype=dtype).element_size()
-        out.append(buf[off:off + nbytes].view(dtype).reshape(shape))
-    return out
+class Collator:
+    """Collates the ranks' results of one sharded job, step after step, without host synchronisation.
+
+    total_rows        G * m_per_graph of the job; rank r owns shard_range(total_rows, r, world)
+    edge_cap          capacity in edge entries of ONE rank's result (the same number on every rank; take it from a probe step)
+    node_id_bound / edge_id_bound / col_bound   exclusive bounds of the values in nodes / edge_index / edge_src (wire widths)
+    dst / all_ranks   the batch is produced on rank `dst` only (gather), or on every rank (all-gather)
+
+    collate(local) takes this rank's (nodes [rows,k], edge_index [2,>=t], edge_ptr [rows+1], edge_src [>=t]) int64 tensors and
+    returns, on the destination(s), (nodes [B,k], edge_index [2,world*edge_cap], edge_ptr [B+1], edge_src [world*edge_cap]) --
+    buffers owned by the collator, overwritten by the next call -- and None elsewhere."""
+
+    def __init__(self, total_rows, k, mode, node_id_bound, edge_id_bound, col_bound, edge_cap, device, group=None, dst=0,
+                 all_ranks=False, world=None, rank=None):
+        self.group, self.dst, self.all_ranks = group, dst, all_ranks
+        if world is None:
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        else:                                                  # explicit geometry: pack / unpack without a process group (tests)
+            self.world, self.rank = int(world), int(rank)
+        if self.world > 64:
+            raise RuntimeError("Collator: at most 64 ranks")
+        self.k, self.total_rows, self.edge_cap = int(k), int(total_rows), int(edge_cap)
+        self.dev = torch.device(device)
+        spans = [shard_range(total_rows, r, self.world) for r in range(self.world)]
+        self.row_off = [s[0] for s in spans] + [self.total_rows]
+        self.rows = spans[self.rank][1]
+        self.rows_cap = max(s[1] for s in spans)
+        self.nd, self.ed, self.sd = _wire_dtypes(k, mode, node_id_bound, edge_id_bound, col_bound)
+        self.nb, self.eb, self.sb = (torch.empty((), dtype=d).element_size() for d in (self.nd, self.ed, self.sd))
+        self.sec, self.nbytes = _layout(self.k, self.nb, self.eb, self.sb, self.rows_cap, self.edge_cap)
+        self.msg = torch.zeros(self.nbytes, dtype=torch.uint8, device=self.dev)
+        self._views = self._sections(self.msg)
+        self._views[0][0] = self.rows                          # header: this rank's row count never changes
+        self.is_dst = all_ranks or self.rank == dst
+        if self.is_dst:
+            self.inbox = torch.zeros((self.world, self.nbytes), dtype=torch.uint8, device=self.dev)
+            cap = self.world * self.edge_cap
+            self.out_nodes = torch.empty((self.total_rows, self.k), dtype=torch.int64, device=self.dev)
+            self.out_eptr = torch.empty((self.total_rows + 1,), dtype=torch.int64, device=self.dev)
+            self.out_eidx = torch.empty((2, max(cap, 1)), dtype=torch.int64, device=self.dev)
+            self.out_esrc = torch.empty((max(cap, 1),), dtype=torch.int64, device=self.dev)
+            self._row_off_c = (C.c_int64 * (self.world + 1))(*self.row_off)
+            self._lanes = torch.arange(self.edge_cap, dtype=torch.int64, device=self.dev) if self.dev.type != "cuda" else None
+
+    def _sections(self, buf):
+        """typed views (header, nodes, edge_ptr, edge_index, edge_src) of one message"""
+        o_n, o_p, o_e, o_s = self.sec
+        rc, ec, k = self.rows_cap, self.edge_cap, self.k
+        head = buf[0:16].view(torch.int64)
+        nodes = buf[o_n:o_n + rc * k * self.nb].view(self.nd).reshape(rc, k)
+        eptr = buf[o_p:o_p + (rc + 1) * 4].view(torch.int32)
+        eidx = buf[o_e:o_e + 2 * ec * self.eb].view(self.ed).reshape(2, ec)
+        esrc = buf[o_s:o_s + ec * self.sb].view(self.sd)
+        return head, nodes, eptr, eidx, esrc
+
+    # -- this rank's rows -> its message (dtype-converting copies straight into the message; nothing is synchronised) ----------
+    def pack(self, local):
+        nodes, edge_index, edge_ptr, edge_src = local
+        rows = self.rows
+        if nodes.size(0) != rows:
+            raise RuntimeError(f"Collator: rank {self.rank} owns {rows} rows, got {nodes.size(0)}")
+        head, w_nodes, w_eptr, w_eidx, w_esrc = self._views
+        head[1:2].copy_(edge_ptr[rows:rows + 1])
+        w_nodes[:rows].copy_(nodes)
+        w_eptr[:rows + 1].copy_(edge_ptr)                      # values < 2^32: stored as the low 32 bits
+        n = min(self.edge_cap, edge_index.size(1))             # whatever lies beyond the step's total is never read
+        if n:
+            w_eidx[:, :n].copy_(edge_index[:, :n])
+            w_esrc[:n].copy_(edge_src[:n])
+        return self.msg
+
+    def exchange(self):
+        if self.all_ranks:
+            dist.all_gather_into_tensor(self.inbox, self.msg.reshape(1, -1), group=self.group)
+        else:
+            blocks = [self.inbox[r] for r in range(self.world)] if self.is_dst else None
+            dist.gather(self.msg, blocks, dst=self.dst, group=self.group)
+
+    # -- `world` messages -> the batch ---------------------------------------------------------------------------------------
+    def unpack(self):
+        if not self.is_dst:
+            return None
+        if self.dev.type == "cuda":
+            from ._lib import check, lib
+            check(lib.ugs_collate_unpack(self.inbox.data_ptr(), self.world, self._row_off_c, self.k, self.nb, self.eb, self.sb,
+                                         self.rows_cap, self.edge_cap, self.out_nodes.data_ptr(), self.out_eidx.data_ptr(),
+                                         self.out_eidx.stride(0), self.out_eptr.data_ptr(), self.out_esrc.data_ptr(),
+                                         torch.cuda.current_stream(self.dev).cuda_stream))
+        else:
+            self._unpack_torch()
+        return self.out_nodes, self.out_eidx, self.out_eptr, self.out_esrc
+
+    def _unpack_torch(self):
+        """the same result with torch operations (CPU / gloo): the offsets stay tensors, rank blocks are placed in rank order
+        with computed indices, a block's slack beyond its total is overwritten by the next rank's entries"""
+        off = torch.zeros((), dtype=torch.int64, device=self.dev)
+        for r in range(self.world):
+            head, w_nodes, w_eptr, w_eidx, w_esrc = self._sections(self.inbox[r])
+            r0, r1 = self.row_off[r], self.row_off[r + 1]
+            rows = r1 - r0
+            self.out_nodes[r0:r1].copy_(w_nodes[:rows])
+            lp = w_eptr[:rows].to(torch.int64) & 0xFFFFFFFF
+            torch.add(lp, off, out=self.out_eptr[r0:r1])
+            if self.edge_cap:
+                idx = self._lanes + off
+                blk = w_eidx.to(torch.int64)
+                if self.ed == torch.uint8:
+                    blk = blk & 0xFF
+                self.out_eidx.index_copy_(1, idx, blk)
+                self.out_esrc.index_copy_(0, idx, w_esrc.to(torch.int64))
+            off = off + head[1]
+        self.out_eptr[self.total_rows:].copy_(off.reshape(1))
+
+    def collate(self, local):
+        self.pack(local)
+        self.exchange()
+        return self.unpack()
+
+    __call__ = collate
 
 
 def collate(local, k, mode, node_id_bound, edge_id_bound, col_bound, group=None, dst=0, all_ranks=False):
-    """Collates per-rank results (nodes [r,k], edge_index [2,>=t], edge_ptr [r+1], edge_src [>=t]; int64, rank order =
-    row order) into the full (nodes, edge_index, edge_ptr, edge_src) on rank `dst` (None elsewhere), or on every rank if
-    `all_ranks`.  Works on the tensors' own device (GPU with nccl/RCCL, CPU with gloo)."""
+    """One-off collation with exact-size results (setup cost and two host round trips per call: use a Collator in a loop).
+    Per-rank (nodes [r,k], edge_index [2,>=t], edge_ptr [r+1], edge_src [>=t]) -> the full tensors on `dst` / every rank."""
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
     nodes, edge_index, edge_ptr, edge_src = local
     dev = nodes.device
-    rows = nodes.size(0)
-    # 1. sizes (one tiny all-gather; the host needs them to size the messages)
-    mine = torch.stack([torch.tensor(rows, dtype=torch.int64, device=dev), edge_ptr[-1].to(torch.int64)]).reshape(1, 2)
+    mine = torch.stack([torch.tensor(nodes.size(0), dtype=torch.int64, device=dev), edge_ptr[-1].to(torch.int64)]).reshape(1, 2)
     sizes = torch.empty((world, 2), dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(sizes, mine, group=group)
-    sizes = sizes.cpu().tolist()
-    max_rows, max_tot = max(s[0] for s in sizes), max(s[1] for s in sizes)
-    tot = sizes[rank][1]
-    nd, ed, sd = _wire_dtypes(k, mode, node_id_bound, edge_id_bound, col_bound)
-    # 2. narrow + pad to the common message shape
-    w_nodes = torch.zeros((max_rows, k), dtype=nd, device=dev)
-    w_nodes[:rows] = nodes.to(nd)
-    w_counts = torch.zeros((max_rows,), dtype=torch.int32, device=dev)
-    w_counts[:rows] = (edge_ptr[1:] - edge_ptr[:-1]).to(torch.int32)
-    w_eidx = torch.zeros((2, max_tot), dtype=ed, device=dev)
-    w_eidx[:, :tot] = edge_index[:, :tot].to(ed)
-    w_esrc = torch.zeros((max_tot,), dtype=sd, device=dev)
-    w_esrc[:tot] = edge_src[:tot].to(sd)
-    msg, layout, nbytes = _pack([w_nodes, w_counts, w_eidx, w_esrc])
-    # 3. the exchange step
-    if all_ranks:
-        gathered = torch.empty((world, nbytes), dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(gathered, msg.reshape(1, -1), group=group)
-        blocks = [gathered[r] for r in range(world)]
-    else:
-        blocks = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
-        dist.gather(msg, blocks, dst=dst, group=group)
-        if rank != dst:
-            return None
-    # 4. widen + compact in rank (= row) order
-    n_l, c_l, e_l, s_l = [], [], [], []
-    for r in range(world):
-        bn, bc, be, bs = _unpack(blocks[r], layout)
-        rr, tt = sizes[r]
-        n_l.append(bn[:rr])
-        c_l.append(bc[:rr])
-        e_l.append(be[:, :tt])
-        s_l.append(bs[:tt])
-    out_nodes = torch.cat(n_l).to(torch.int64)
-    counts = torch.cat(c_l).to(torch.int64)
-    out_eptr = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(counts, 0, out=out_eptr[1:])
-    out_eidx = torch.cat(e_l, dim=1).to(torch.int64)
-    out_esrc = torch.cat(s_l).to(torch.int64)
-    return out_nodes, out_eidx, out_eptr, out_esrc
+    sizes = sizes.cpu()
+    total_rows, edge_cap = int(sizes[:, 0].sum()), int(sizes[:, 1].max())
+    spans = [shard_range(total_rows, r, world)[1] for r in range(world)]
+    if spans != sizes[:, 0].tolist():
+        raise RuntimeError("collate: the ranks' row counts are not the shard_range split of their sum")
+    c = Collator(total_rows, k, mode, node_id_bound, edge_id_bound, col_bound, edge_cap, dev, group=group, dst=dst, all_ranks=all_ranks)
+    res = c.collate(local)
+    if res is None:
+        return None
+    out_nodes, out_eidx, out_eptr, out_esrc = res
+    tot = int(sizes[:, 1].sum())
+    return out_nodes, out_eidx[:, :tot].contiguous(), out_eptr, out_esrc[:tot].contiguous()
 
 
 def default_row_sampler(edge_index, ptr, k):

@@ -50,7 +50,23 @@ def _worker(rank, world, port, mode, all_ranks, q):
             ok = (not all_ranks) and rank != 0
         else:
             ok = all(np.array_equal(a.numpy(), b) and a.dtype == torch.int64 for a, b in zip(res, full))
+        # steady state: ONE Collator, several steps with different totals, no host round trip inside collate()
         begin, count = ud.shard_range(5 * m, rank, world)
+        fulls = [oracle.sample_batch(ei, ptr, m, k, mode, s) for s in (1, 2, 3)]
+        cap = max(int(f[2][begin + count] - f[2][begin]) for f in fulls)
+        cap_t = torch.tensor([cap])
+        dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
+        node_bound = int(ptr[-1])
+        col = ud.Collator(5 * m, k, mode, node_bound, max(node_bound, m * k), ei.shape[1], int(cap_t.item()) + 3, "cpu", dst=0, all_ranks=all_ranks)
+        for f in fulls:
+            full = f
+            res = col.collate(row_sampler(m, mode, 0, begin, count))
+            if res is None:
+                ok = ok and (not all_ranks) and rank != 0
+            else:
+                tot = int(res[2][-1])
+                ok = ok and tot == int(f[2][-1]) and np.array_equal(res[0].numpy(), f[0]) and np.array_equal(res[2].numpy(), f[2]) \
+                    and np.array_equal(res[1][:, :tot].numpy(), f[1]) and np.array_equal(res[3][:tot].numpy(), f[4])
         q.put((rank, bool(ok), begin, count))
     finally:
         dist.destroy_process_group()

@@ -131,3 +131,39 @@ def test_one_plan_on_two_streams():
     w5 = oracle.sample_batch(ei, ptr, 2000, k, "sample", 5)
     for a, b in zip(got, w5):
         assert np.array_equal(a.numpy(), b)
+
+
+@pytest.mark.parametrize("mode,world", [("sample", 3), ("global", 2), ("graph", 5)])
+def test_collation_kernels_equal_the_torch_path_and_the_oracle(mode, world):
+    """ugs_collate_unpack (HIP) against the torch-operation path of the same Collator and against the single-process result:
+    `world` ranks' messages are packed on the GPU, placed in the destination's inbox by hand (no process group needed), unpacked."""
+    import torch
+    import oracle
+    import ugs_workloads as wl
+    from ugs_sampler import distributed as ud
+    ei, ptr = wl.tu_batch(18, 20, 6)
+    m, k = 9, 4
+    G = len(ptr) - 1
+    dev = torch.device("cuda", torch.cuda.current_device())
+    node_bound = int(ptr[-1])
+    for seed in (1, 2):
+        full = oracle.sample_batch(ei, ptr, m, k, mode, seed)
+        nodes, eidx, eptr, _, esrc = full
+        spans = [ud.shard_range(G * m, r, world) for r in range(world)]
+        cap = max(int(eptr[b + c] - eptr[b]) for b, c in spans) + 5
+        mk = lambda r, d: ud.Collator(G * m, k, mode, node_bound, max(node_bound, m * k), ei.shape[1], cap, d, dst=0, world=world, rank=r)
+        dst_gpu, dst_cpu = mk(0, dev), mk(0, "cpu")
+        for r, (b, c) in enumerate(spans):
+            e0, e1 = int(eptr[b]), int(eptr[b + c])
+            junk = np.full((2, cap - (e1 - e0)), -9, dtype=np.int64)                      # capacity slack beyond the rank's total
+            local = (torch.from_numpy(nodes[b:b + c].copy()), torch.from_numpy(np.concatenate([eidx[:, e0:e1], junk], axis=1)),
+                     torch.from_numpy((eptr[b:b + c + 1] - e0).copy()), torch.from_numpy(np.concatenate([esrc[e0:e1], junk[0]])))
+            msg = mk(r, dev).pack(tuple(t.to(dev) for t in local))
+            dst_gpu.inbox[r].copy_(msg)
+            dst_cpu.inbox[r].copy_(msg.cpu())
+        got = [t.cpu().numpy() for t in dst_gpu.unpack()]
+        ref = [t.numpy() for t in dst_cpu.unpack()]
+        tot = int(eptr[-1])
+        assert int(got[2][-1]) == tot == int(ref[2][-1])
+        for g, r_, w in ((got[0], ref[0], nodes), (got[2], ref[2], eptr), (got[1][:, :tot], ref[1][:, :tot], eidx), (got[3][:tot], ref[3][:tot], esrc)):
+            assert np.array_equal(g, w) and np.array_equal(r_, w)
