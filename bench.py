@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- k-subgraphs sampled per second on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c5_er_1m|c2_mutag_b1024|c3_proteins_b8192|c4_qm9_b65536]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak]
+                    [--workload c5_er_1m|c2_mutag_b1024|c3_proteins_b8192|c4_qm9_b65536|er_<n>_<cols>_<m>_<k>]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (fresh child processes, before anything
+touches a GPU) and relays rank 0's line.
 
 A *step* is one pass of the hot path over one batch: walk kernel(s) + scan + fill kernel, producing the reference's
 tensors (nodes, edge_index, edge_ptr, edge_src) in HBM from a plan (preprocessed graph batch) that is already resident
 in HBM -- the state the reference is in with a warm preprocessing LRU.  Default workload: BASELINE.json configs[4], the
-Erdos-Renyi graph |V|=1M, 20M columns, k=8, 1M samples per GPU (weak scaling: N GPUs produce N*1M rows of the same job,
-rank r owning rows [r*1M, (r+1)*1M); for N>1 every step also collates the batch on rank 0 over RCCL -- on a side
+Erdos-Renyi graph |V|=1M, 20M columns, k=8, batch = 1M samples.
+  strong scaling (default): the N ranks split THE batch -- rank r samples rows [r*B/N, (r+1)*B/N) (legal
+      because row i depends only on (seed, i), reference src/sampler.cpp:158-161) -- and the batch is collated on rank 0;
+  weak scaling: every rank adds B rows of the same job (N*B rows per step), collated on rank 0.
+For N > 1 every step collates the batch on rank 0 over RCCL (ugs_sampler.distributed.Collator: no host round trip) on a side
 stream, double-buffered, so the collation of batch s overlaps the sampling of batch s+1; all K collations are inside the
-timed region).
-The seed changes every step (42 + step) so no step can reuse a previous step's output.
+timed region.  The seed changes every step (42 + step) so no step can reuse a previous step's output.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,10 +30,137 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ss-gnn_amd"))
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, chip table)
+EDGE_MODE = {"sample": "local", "graph": "flat", "global": "global"}
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c5_er_1m")
+    ap.add_argument("--mode", default="sample")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="rows timed on the 1-core CPU baseline (default: sized per workload)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-cpu-reference", action="store_true", help="skip timing the reference C++ itself (oracle/_ref) on the headline workload; its preprocessing takes about half a minute on C5")
+    ap.add_argument("--walk-share", type=int, default=80, help="percent of each CU the walk kernels occupy while a collation runs beside them (N > 1)")
+    ap.add_argument("--force-collate", action="store_true", help="run the multi-GPU collation path even with one rank (rehearsal)")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# self-launch: N ranks as fresh child processes (nothing in this parent has touched a GPU: torch is not even imported)
+# ------------------------------------------------------------------------------------------------------------------------
+def launch_ranks(n):
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:       # rank 0 is gone; a rank stuck in a collective is ended by its own PID
+            p.kill()
+            rcs.append(p.wait())
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [rc for rc in rcs if rc != 0]
+    return bad[0] if bad else 0
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# CPU baseline workers (the oracle is the CHECKER; here it is only the reported CPU baseline)
+# ------------------------------------------------------------------------------------------------------------------------
+def usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                             # cgroup v2 quota of the container / box share
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:   # noqa: BLE001
+        pass
+    return max(1, n)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:   # noqa: BLE001
+        pass
+    return "unknown"
+
+
+def cpu_worker(spec):
+    """child process of the all-cores leg: builds the oracle's preprocessing, says 'ready', waits for 'go', samples its row
+    range of the job (disjoint i-ranges: row i depends only on (seed, i)), prints the seconds that took."""
+    workload, mode, begin, count, m_total = spec.split(",")
+    begin, count, m_total = int(begin), int(count), int(m_total)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    import ugs_workloads as wl
+    ei, ptr, m, k = wl.workload(workload)
+    G = len(ptr) - 1
+    if G == 1:
+        P = oracle.Preproc(ei, int(ptr[1]), k)
+        run = lambda: P.sample(m_total, k, EDGE_MODE[mode], 0, 42, begin, begin + count)           # noqa: E731
+    else:                                            # batches: the worker takes `count` samples per graph starting at sample `begin`
+        cache = oracle.Cache()
+        oracle.sample_batch(ei, ptr, 1, k, mode, 42, cache=cache)
+        run = lambda: oracle.sample_batch(ei, ptr, count, k, mode, 42 + begin, cache=cache)  # noqa: E731
+    print("ready", flush=True)
+    sys.stdin.readline()
+    t = time.perf_counter()
+    run()
+    print(f"done {time.perf_counter() - t:.6f}", flush=True)
+
+
+def cpu_all_cores(workload, mode, m_total, G, rows_per_worker):
+    cores = usable_cores()
+    procs = []
+    for w in range(cores):
+        spec = f"{workload},{mode},{w * rows_per_worker},{rows_per_worker},{m_total}"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", spec], stdin=subprocess.PIPE,
+                                      stdout=subprocess.PIPE, text=True))
+    try:
+        for p in procs:
+            if p.stdout.readline().strip() != "ready":
+                raise RuntimeError("CPU worker failed to start")
+        t = time.perf_counter()
+        for p in procs:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        secs = [float(p.stdout.readline().split()[1]) for p in procs]
+        wall = time.perf_counter() - t
+    finally:
+        for p in procs:
+            try:
+                p.stdin.close()
+            except Exception:   # noqa: BLE001
+                pass
+            p.wait()
+    rows = cores * rows_per_worker * (G if G > 1 else 1)
+    return {"value": round(rows / wall, 1), "unit": "k-subgraphs/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"{cores} processes x {rows_per_worker} {'samples per graph' if G > 1 else 'rows'} of the same job (disjoint sample-index ranges), "
+                      f"wall {wall:.2f}s from a common start, slowest worker {max(secs):.2f}s; preprocessing excluded",
+            "per_core": round(rows / wall / cores, 1)}
 
 
 def csr_degrees(ei, n_total):
@@ -48,7 +182,111 @@ def split_algorithmic_bytes(nodes, edge_ptr, k, deg):
     return float(walk.mean()), float(fill.mean())
 
 
+class Job:
+    """One sharded sampling job on this rank: buffers, the step function and (N > 1) the collation on a side stream."""
+
+    def __init__(self, torch, dist, ud, plan, args, G, m_total, k, rank, world, dev, node_bound, n_cols, use_collate):
+        self.torch, self.plan, self.args, self.k, self.m_total = torch, plan, args, k, m_total
+        self.total_rows = G * m_total
+        self.row_begin, self.row_count = ud.shard_range(self.total_rows, rank, world)
+        self.use_collate = use_collate
+        nsets = 2 if use_collate else 1       # double buffering: step s samples into set s%2 while set (s-1)%2 is collated
+        self.nsets = nsets
+        rc = self.row_count
+        self.nodes = [torch.empty((rc, k), dtype=torch.int64, device=dev) for _ in range(nsets)]
+        self.eptr = [torch.empty((rc + 1,), dtype=torch.int64, device=dev) for _ in range(nsets)]
+        # edge capacity from one synchronous probe step (+5%); identical on every rank
+        _, _, tot = plan.walk(m_total, args.mode, 41, self.row_begin, rc, out=(self.nodes[0], self.eptr[0]), sync=True)
+        cap_t = torch.tensor([int(tot * 1.05) + 4096], dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
+        self.cap = int(cap_t.item())
+        self.eidx = [torch.empty((2, self.cap), dtype=torch.int64, device=dev) for _ in range(nsets)]
+        self.esrc = [torch.empty((self.cap,), dtype=torch.int64, device=dev) for _ in range(nsets)]
+        self.main = torch.cuda.current_stream()
+        if use_collate:
+            self.side = torch.cuda.Stream(device=dev)
+            self.collator = ud.Collator(self.total_rows, k, args.mode, node_bound, max(node_bound, m_total * k), n_cols, self.cap, dev, dst=0)
+            self.ev_sampled = [torch.cuda.Event() for _ in range(nsets)]
+            self.ev_collated = [torch.cuda.Event() for _ in range(nsets)]
+            self.collated_once = [False] * nsets
+            self.cev = []                      # (start, end) events of every collation on the side stream
+        self.totals = None
+
+    def sample(self, i):
+        """walk + scan + fill of step i into buffer set i % nsets (asynchronous, main stream)"""
+        b = i % self.nsets
+        if self.use_collate and self.collated_once[b]:
+            self.main.wait_event(self.ev_collated[b])            # the set is free once its previous batch has been packed
+        self.plan.walk(self.m_total, self.args.mode, 42 + i, self.row_begin, self.row_count, out=(self.nodes[b], self.eptr[b]), sync=False)
+        self.plan.fill(self.m_total, self.nodes[b], self.eptr[b], None, self.args.mode, self.row_begin, out=(self.eidx[b], self.esrc[b]))
+        if self.totals is not None:
+            self.totals[i] = self.eptr[b][-1]
+        if self.use_collate:
+            self.ev_sampled[b].record(self.main)
+
+    def collate_step(self, i, timed):
+        """the one exchange step: collate batch i on rank 0 (side stream, overlaps the sampling of batch i+1)"""
+        torch, b = self.torch, i % self.nsets
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_sampled[b])
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.side)
+            res = self.collator.collate((self.nodes[b], self.eidx[b], self.eptr[b], self.esrc[b]))
+            if timed:
+                e1.record(self.side)
+                self.cev.append((e0, e1))
+            self.ev_collated[b].record(self.side)
+        self.collated_once[b] = True
+        return res
+
+    def run_steps(self, first, count, timed=False):
+        """`count` complete steps: every batch sampled AND (multi-GPU) collated inside the call"""
+        res = None
+        for i in range(first, first + count):
+            self.sample(i)
+            if self.use_collate and i > first:
+                self.collate_step(i - 1, timed)
+        if self.use_collate and count > 0:
+            res = self.collate_step(first + count - 1, timed)
+            self.side.synchronize()
+        return res
+
+
+def timed_run(torch, dist, job, steps, warmup, world, dev):
+    job.totals = torch.zeros((steps + warmup + 1,), dtype=torch.int64, device=dev)
+    job.run_steps(0, warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    job.run_steps(warmup, steps, timed=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    el_t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
+    tmax = int(job.totals.max().item())
+    if tmax > job.cap:
+        raise SystemExit(f"edge capacity {job.cap} too small for {tmax}: result invalid")
+    cms = None
+    if job.use_collate and job.cev:
+        cms = sum(a.elapsed_time(b) for a, b in job.cev) / len(job.cev)
+    return float(el_t.item()), cms
+
+
 def main():
+    args = parse_args()
+    if args.cpu_worker:
+        return cpu_worker(args.cpu_worker)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+
     # Libraries (RCCL prints a version banner) must not pollute stdout: fd 1 is pointed at stderr for the whole run and the
     # single JSON line goes to the saved, real stdout at the end.
     sys.stdout.flush()
@@ -57,18 +295,6 @@ def main():
 
     def emit(line):
         os.write(real_stdout, (line + "\n").encode())
-
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c5_er_1m")
-    ap.add_argument("--mode", default="sample")
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="rows timed on the CPU baseline (default: sized per workload)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--force-collate", action="store_true", help="run the multi-GPU collation path even with one rank (rehearsal)")
-    args = ap.parse_args()
 
     import numpy as np
     import torch
@@ -82,7 +308,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.force_collate:
@@ -100,92 +326,33 @@ def main():
     t2 = time.time()
     info = plan.info()
     if rank == 0:
-        log(f"[bench] workload {args.workload}: G={G} cols={ei.shape[1]} k={k} m/GPU={m}; generate {t1 - t0:.1f}s, "
-            f"preprocess+upload {t2 - t1:.1f}s, plan {info['device_bytes'] / 1e6:.0f} MB in HBM, tier {info['tier']}")
-    rows_local = G * m
-    m_total = m * world                      # weak scaling: every GPU adds m samples per graph to the job
-    total_rows = G * m_total
-    row_begin, row_count = ud.shard_range(total_rows, rank, world)
-    assert row_count == rows_local
-
-    use_collate = world > 1 or args.force_collate
-    nsets = 2 if use_collate else 1          # double buffering: step s samples into set s%2 while set (s-1)%2 is collated
-    nodes_bufs = [torch.empty((row_count, k), dtype=torch.int64, device=dev) for _ in range(nsets)]
-    eptr_bufs = [torch.empty((row_count + 1,), dtype=torch.int64, device=dev) for _ in range(nsets)]
-    nodes_buf, eptr_buf = nodes_bufs[0], eptr_bufs[0]
-    # edge capacity from one synchronous probe step (+5%); identical on every rank
-    _, _, tot = plan.walk(m_total, args.mode, 41, row_begin, row_count, out=(nodes_buf, eptr_buf), sync=True)
-    cap_t = torch.tensor([int(tot * 1.05) + 4096], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
-    cap = int(cap_t.item())
-    eidx_bufs = [torch.empty((2, cap), dtype=torch.int64, device=dev) for _ in range(nsets)]
-    esrc_bufs = [torch.empty((cap,), dtype=torch.int64, device=dev) for _ in range(nsets)]
-    totals = torch.zeros((args.steps + args.warmup + 1,), dtype=torch.int64, device=dev)
+        log(f"[bench] workload {args.workload}: G={G} cols={ei.shape[1]} k={k} batch={G * m}; generate {t1 - t0:.1f}s, "
+            f"preprocess+upload {t2 - t1:.1f}s, plan {info['device_bytes'] / 1e6:.0f} MB in HBM, tier {info['tier']}, {world} rank(s), {args.scaling} scaling")
     node_bound = int(ptr[-1])
-    edge_bound = max(node_bound, m_total * k)
-    main_stream = torch.cuda.current_stream()
-    side = torch.cuda.Stream(device=dev) if use_collate else None
-    ev_sampled = [torch.cuda.Event() for _ in range(nsets)]
-    ev_collated = [torch.cuda.Event() for _ in range(nsets)]
-    collated_once = [False] * nsets
+    use_collate = world > 1 or args.force_collate
+    m_total = m * world if args.scaling == "weak" else m
+    if use_collate:
+        plan.set_walk_share(args.walk_share)              # room on every CU for the collation + RCCL kernels of the previous batch
+    job = Job(torch, dist, ud, plan, args, G, m_total, k, rank, world, dev, node_bound, ei.shape[1], use_collate)
+    total_rows, row_begin, row_count = job.total_rows, job.row_begin, job.row_count
 
-    def sample(i):
-        """walk + scan + fill of step i into buffer set i % nsets (asynchronous, main stream)"""
-        b = i % nsets
-        if use_collate and collated_once[b]:
-            main_stream.wait_event(ev_collated[b])            # the set is free once its previous batch has been collated
-        plan.walk(m_total, args.mode, 42 + i, row_begin, row_count, out=(nodes_bufs[b], eptr_bufs[b]), sync=False)
-        plan.fill(m_total, nodes_bufs[b], eptr_bufs[b], None, args.mode, row_begin, out=(eidx_bufs[b], esrc_bufs[b]))
-        totals[i] = eptr_bufs[b][-1]
-        if use_collate:
-            ev_sampled[b].record(main_stream)
-
-    def collate_step(i):
-        """the one exchange step: collate batch i on rank 0 (side stream, overlaps the sampling of batch i+1)"""
-        b = i % nsets
-        with torch.cuda.stream(side):
-            side.wait_event(ev_sampled[b])
-            res = ud.collate((nodes_bufs[b], eidx_bufs[b], eptr_bufs[b], esrc_bufs[b]), k, args.mode, node_bound, edge_bound,
-                             ei.shape[1], dst=0)
-            ev_collated[b].record(side)
-        collated_once[b] = True
-        return res
-
-    def run_steps(first, count):
-        """`count` complete steps: every batch sampled AND (multi-GPU) collated inside the call"""
-        if count <= 0:
-            return
-        for i in range(first, first + count):
-            sample(i)
-            if use_collate and i > first:
-                collate_step(i - 1)
-        if use_collate:
-            collate_step(first + count - 1)
-            side.synchronize()
-
-    run_steps(0, args.warmup)
+    plan.set_timing(False)
+    job.run_steps(0, 1)                                   # first touch of every buffer outside the event-timed region
     torch.cuda.synchronize()
     plan.set_timing(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    run_steps(args.warmup, args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_start
-    el_t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
-    elapsed = float(el_t.item())
+    elapsed, collate_ms = timed_run(torch, dist, job, args.steps, args.warmup, world, dev)
     timing = plan.get_timing()
     plan.set_timing(False)
-    tmax = int(totals.max().item())
-    if tmax > cap:
-        raise SystemExit(f"edge capacity {cap} too small for {tmax}: result invalid")
+
+    extras = {}
+    if world > 1 and args.scaling == "strong" and not args.no_extras:
+        # the other scaling mode, short: every rank adds a whole batch (N*B rows per step collated on rank 0)
+        wjob = Job(torch, dist, ud, plan, args, G, m * world, k, rank, world, dev, node_bound, ei.shape[1], True)
+        wsteps = max(3, args.steps // 2)
+        wel, wcms = timed_run(torch, dist, wjob, wsteps, 2, world, dev)
+        extras["weak_scaling"] = {"value": round(wjob.total_rows * wsteps / wel, 1), "ms_per_step": round(wel / wsteps * 1e3, 4), "steps": wsteps,
+                                  "global_rows": wjob.total_rows, "rows_per_gpu": wjob.row_count, "collate_ms_per_step": round(wcms, 4) if wcms else None}
+        del wjob
 
     if rank != 0:
         dist.barrier()
@@ -194,13 +361,17 @@ def main():
 
     value = total_rows * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
+    # timing["walk"] etc. include the warm-up steps of timed_run: per-launch means
     walk_ms = timing["walk"][0] / max(timing["walk"][1], 1)
     scan_ms = timing["scan"][0] / max(timing["scan"][1], 1)
     fill_ms = timing["fill"][0] / max(timing["fill"][1], 1)
     launch = plan.last_launch()
 
-    # ---- algorithmic bytes from a reference step (seed 42) and parity of its first rows against the CPU oracle -----
-    plan.walk(m_total, args.mode, 42, row_begin, row_count, out=(nodes_buf, eptr_buf), sync=True)
+    # ---- a reference step (seed 42): algorithmic bytes, and parity of ALL FOUR tensors of its first rows against the oracle ----
+    nodes_buf, eptr_buf, eidx_buf, esrc_buf = job.nodes[0], job.eptr[0], job.eidx[0], job.esrc[0]
+    _, _, tot42 = plan.walk(m_total, args.mode, 42, row_begin, row_count, out=(nodes_buf, eptr_buf), sync=True)
+    plan.fill(m_total, nodes_buf, eptr_buf, None, args.mode, row_begin, out=(eidx_buf, esrc_buf))
+    torch.cuda.synchronize()
     nodes_h = nodes_buf.cpu().numpy()
     eptr_h = eptr_buf.cpu().numpy()
     deg = csr_degrees(ei, node_bound)
@@ -210,11 +381,11 @@ def main():
     gpu_ms = walk_ms + scan_ms + fill_ms
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written from separate rocprofv3 --pmc passes of this command
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and world == 1:
         try:
             with open(tpath) as f:
                 traffic = json.load(f).get(args.workload, {}).get("walk_kernel_hbm_bytes_per_launch")
-        except Exception:
+        except Exception:   # noqa: BLE001
             traffic = None
     roofline = {"bound": "hbm", "kernel": launch["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
@@ -225,22 +396,26 @@ def main():
                          "fill_kernel_ms": round(fill_ms, 4), "scan_ms": round(scan_ms, 4)}}
 
     cpu_baseline = None
+    cpu_all = None
     parity_rows = 0
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle   # the checker, used here only as the reported CPU baseline and for a parity spot check
+        import oracle   # the checker, used here only as the reported CPU baseline and for a parity check
         n_cpu = args.cpu_sample if args.cpu_sample > 0 else (100_000 if args.workload.startswith("c5") else min(total_rows, 400_000))
         if G == 1:
             tp = time.time()
             P = oracle.Preproc(ei, int(ptr[1]), k)
             tp = time.time() - tp
-            n_cpu = min(n_cpu, m_total)
+            n_cpu = min(n_cpu, row_count)
             tc = time.perf_counter()
-            o_nodes, o_eidx, o_eptr, o_esrc = P.sample(m_total, k, {"sample": "local", "graph": "flat", "global": "global"}[args.mode], 0, 42, 0, n_cpu)
+            o_nodes, o_eidx, o_eptr, o_esrc = P.sample(m_total, k, EDGE_MODE[args.mode], 0, 42, row_begin, row_begin + n_cpu)
             tc = time.perf_counter() - tc
-            sample_desc = f"rows [0,{n_cpu}) of the same {m_total}-row job on the same graph, seed 42; preprocessing ({tp:.1f}s) excluded like the warm-cache GPU plan"
+            sample_desc = f"rows [{row_begin},{row_begin + n_cpu}) of the same {m_total}-row job on the same graph, seed 42; preprocessing ({tp:.1f}s) excluded like the warm-cache GPU plan"
             parity_rows = n_cpu
-            assert np.array_equal(o_nodes, nodes_h[:n_cpu]) and np.array_equal(o_eptr, eptr_h[: n_cpu + 1]), "GPU rows differ from the CPU oracle"
+            ne = int(o_eptr[-1])
+            assert int(eptr_h[n_cpu]) == ne and np.array_equal(o_nodes, nodes_h[:n_cpu]) and np.array_equal(o_eptr, eptr_h[: n_cpu + 1]), "GPU rows differ from the CPU oracle"
+            assert np.array_equal(o_eidx, eidx_buf[:, :ne].cpu().numpy()) and np.array_equal(o_esrc, esrc_buf[:ne].cpu().numpy()), "GPU edges differ from the CPU oracle"
+            P.close()
         else:
             cache = oracle.Cache()
             oracle.sample_batch(ei, ptr, 1, k, args.mode, 42, cache=cache)          # warm the LRU (preprocessing excluded)
@@ -250,31 +425,69 @@ def main():
             tc = time.perf_counter() - tc
             n_cpu = m_cpu * G
             sample_desc = f"the same {G}-graph batch with m_per_graph={m_cpu} ({n_cpu} rows), seed 42, warm preprocessing LRU"
-            if m_cpu == m_total:
+            if m_cpu == m_total and world == 1:
                 parity_rows = n_cpu
+                ne = int(o[2][-1])
                 assert np.array_equal(o[0], nodes_h) and np.array_equal(o[2], eptr_h), "GPU rows differ from the CPU oracle"
+                assert np.array_equal(o[1], eidx_buf[:, :ne].cpu().numpy()) and np.array_equal(o[4], esrc_buf[:ne].cpu().numpy()), "GPU edges differ from the CPU oracle"
         cpu_baseline = {"value": round(n_cpu / tc, 1), "unit": "k-subgraphs/s", "cores": 1, "kind": "port",
-                        "sample": sample_desc + "; oracle/ugs_oracle.c (plain-C restatement of the reference algorithm), 1 thread"}
+                        "sample": sample_desc + "; oracle/ugs_oracle.c (plain-C restatement of the reference algorithm), 1 thread", "cpu_model": cpu_model()}
+        cpu_port = None
+        if world == 1 and not args.no_cpu_reference:          # the reference C++ itself, when its prebuilt copy travelled (oracle/_ref)
+            try:
+                cref = reference_on_headline(ei_t, ptr_t, m_total, k, args.mode, min(m_total, 20_000 if G == 1 else m_total), G)
+                if cref is not None:
+                    cpu_port, cpu_baseline = cpu_baseline, cref
+            except Exception as e:   # noqa: BLE001
+                log(f"[bench] reference C++ on the headline workload failed: {e}")
+        if world == 1:
+            try:
+                per = max(1, min(20_000, m_total // usable_cores())) if G == 1 else max(1, min(m_total, 100_000 // G))
+                cpu_all = cpu_all_cores(args.workload, args.mode, m_total, G, per)
+            except Exception as e:   # noqa: BLE001
+                cpu_all = {"error": str(e)[:200]}
+
+    # the collated batch of the last timed step against this rank's own rows (placement check of the exchange step)
+    if use_collate:
+        job.totals = None
+        last = job.run_steps(1000, 1)
+        torch.cuda.synchronize()
+        b = 1000 % job.nsets
+        c_nodes, c_eidx, c_eptr, c_esrc = last
+        assert torch.equal(c_nodes[row_begin:row_begin + row_count], job.nodes[b]), "collated nodes differ"
+        assert torch.equal(c_eptr[row_begin:row_begin + row_count + 1] - c_eptr[row_begin], job.eptr[b]), "collated edge_ptr differs"
+        e0, e1 = int(c_eptr[row_begin]), int(c_eptr[row_begin + row_count])
+        assert torch.equal(c_eidx[:, e0:e1], job.eidx[b][:, : e1 - e0]) and torch.equal(c_esrc[e0:e1], job.esrc[b][: e1 - e0]), "collated edges differ"
 
     out = {"metric": "k_subgraphs_sampled_per_sec", "value": round(value, 1), "unit": "k-subgraphs/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-           "config": {"workload": args.workload, "graphs": G, "columns": int(ei.shape[1]), "k": k, "rows_per_gpu": rows_local,
+           "scaling": args.scaling, "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+           "config": {"workload": args.workload, "graphs": G, "columns": int(ei.shape[1]), "k": k, "rows_per_gpu": row_count,
                       "global_rows": total_rows, "mode": args.mode, "sharding": f"rows{world}" if world > 1 else "none",
-                      "collate": "gather to rank 0 over RCCL every step, overlapped with the next step's sampling" if use_collate else "none (single GPU)"},
-           "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_checked_rows": parity_rows}
+                      "collate": "gather to rank 0 over RCCL every step (fixed-size narrowed messages, device-side offsets, no host round trip), "
+                                 f"overlapped with the next step's sampling (walk kernels on {args.walk_share}% of each CU)" if use_collate else "none (single GPU)"},
+           "collate_ms_per_step": round(collate_ms, 4) if collate_ms is not None else None,
+           "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_port": cpu_port if cpu_baseline else None,
+           "cpu_baseline_all_cores": cpu_all, "parity_checked_rows": parity_rows,
+           "parity_checked_tensors": ["nodes", "edge_ptr", "edge_index", "edge_src"] if parity_rows else []}
+    if extras:
+        out["extras"] = extras
 
-    # ---- secondary workloads (single GPU only, quick): the TU-shaped configurations of BASELINE.json -----------------
+    # ---- secondary measurements (single GPU only, quick) ------------------------------------------------------------------
     if not args.no_extras and world == 1:
-        extras = {}
+        try:
+            out["drop_in_call"] = bench_drop_in(args.workload, ugs_sampler, ei_t, ptr_t, m, k, args.mode, dev, reps=3 if ei.shape[1] > 5_000_000 else 20)
+        except Exception as e:   # noqa: BLE001
+            out["drop_in_call"] = {"error": str(e)[:200]}
+        extras_w = {}
         for name in ("c2_mutag_b1024", "c3_proteins_b8192", "c4_qm9_b65536"):
             if name == args.workload:
                 continue
             try:
-                extras[name] = bench_small(name, ugs_sampler, wl, torch, dev)
+                extras_w[name] = bench_small(name, ugs_sampler, wl, torch, dev)
             except Exception as e:   # noqa: BLE001
-                extras[name] = {"error": str(e)}
-        out["other_workloads"] = extras
+                extras_w[name] = {"error": str(e)}
+        out["other_workloads"] = extras_w
         try:
             out["epsilon_uniform_sampler"] = bench_epsilon(wl, torch)
         except Exception as e:   # noqa: BLE001
@@ -292,9 +505,33 @@ def main():
         dist.destroy_process_group()
 
 
+def bench_drop_in(name, ugs_sampler, ei_t, ptr_t, m, k, mode, dev, reps):
+    """The reference's own call, end to end on the headline workload: ugs_sampler.sample_batch(edge_index, ptr, ...) with host
+    tensors in -- (a) pinned host tensors out (SURVEY.md 8(d) primary definition: outputs host-visible), (b) device tensors out."""
+    import torch
+    rows = (ptr_t.numel() - 1) * m
+    ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode=mode, seed=42)
+    t = time.perf_counter()
+    for r in range(reps):
+        ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode=mode, seed=42 + r)
+    dt_host = (time.perf_counter() - t) / reps
+    ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode=mode, seed=42, device=dev)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for r in range(reps):
+        o = ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode=mode, seed=42 + r, device=dev)
+    torch.cuda.synchronize()
+    dt_dev = (time.perf_counter() - t) / reps
+    del o
+    return {"workload": name, "rows": rows, "host_visible_ms": round(dt_host * 1e3, 3), "host_visible_subgraphs_per_s": round(rows / dt_host, 1),
+            "device_out_ms": round(dt_dev * 1e3, 3), "device_out_subgraphs_per_s": round(rows / dt_dev, 1), "reps": reps,
+            "note": "host tensors in every call (the reference's interface): per call the library assigns columns to graphs, renumbers, hashes (LRU key), "
+                    "looks the plan up, samples, and copies out"}
+
+
 def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
-    """TU-shaped configuration: (a) device-resident plan path, outputs in HBM; (b) the drop-in host call
-    ugs_sampler.sample_batch(...) end to end (slice + hash + LRU lookups, kernels, D2H into pinned tensors)."""
+    """TU-shaped configuration: (a) device-resident plan path, outputs in HBM (per-repetition HIP-event times: median and max);
+    (b) the drop-in host call ugs_sampler.sample_batch(...) end to end (slice + hash + LRU lookups, kernels, D2H into pinned tensors)."""
     import numpy as np
     ei, ptr, m, k = wl.workload(name)
     G = len(ptr) - 1
@@ -311,12 +548,19 @@ def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
         plan.walk(m, "sample", 42 + i, 0, rows, out=(nodes, eptr), sync=False)
         plan.fill(m, nodes, eptr, None, "sample", 0, out=(eidx, esrc))
     torch.cuda.synchronize()
+    evs = []
     t = time.perf_counter()
     for i in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
         plan.walk(m, "sample", 42 + i, 0, rows, out=(nodes, eptr), sync=False)
         plan.fill(m, nodes, eptr, None, "sample", 0, out=(eidx, esrc))
+        b.record()
+        evs.append((a, b))
     torch.cuda.synchronize()
-    dt_dev = (time.perf_counter() - t) / reps
+    dt_wall = (time.perf_counter() - t) / reps
+    per = sorted(a.elapsed_time(b) for a, b in evs)
+    dt_dev = per[len(per) // 2] * 1e-3                                     # median repetition (a single stalled one does not move it)
     # the same step captured once as a HIP graph and replayed (Plan.graph_step)
     dt_graph = None
     try:
@@ -356,7 +600,9 @@ def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
         out_dev = ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode="sample", seed=42, device=dev)
     torch.cuda.synchronize()
     dt_devout = (time.perf_counter() - t) / reps
+    del out_dev
     res = {"rows": rows, "k": k, "device_resident_subgraphs_per_s": round(rows / dt_dev, 1), "device_resident_ms": round(dt_dev * 1e3, 4),
+           "device_resident_ms_max_rep": round(per[-1], 4), "device_resident_ms_wall_mean": round(dt_wall * 1e3, 4),
            "hip_graph_replay_subgraphs_per_s": round(rows / dt_graph, 1) if dt_graph else None,
            "hip_graph_replay_ms": round(dt_graph * 1e3, 4) if dt_graph else None,
            "drop_in_call_subgraphs_per_s": round(rows / dt_host, 1), "drop_in_call_ms": round(dt_host * 1e3, 4),
@@ -384,6 +630,8 @@ def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
                 r = ref.sample_batch(ei_t, ptr_t, m, k, "sample", 42)
                 best = min(best, time.perf_counter() - t)
             g = ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode="sample", seed=42)
+            res["cpu_baseline"] = {"value": round(rows / best, 1), "unit": "k-subgraphs/s", "cores": 1, "kind": "reference",
+                                   "sample": "the whole batch, best of 3, warm preprocessing LRU; oracle/_ref (the reference's own sources)"}
             res["reference_cpp_subgraphs_per_s"] = round(rows / best, 1)
             res["bit_exact_vs_reference_cpp"] = bool(all(torch.equal(a, b) for a, b in zip(g, r)))
     except Exception as e:   # noqa: BLE001
@@ -437,6 +685,36 @@ def load_prebuilt_reference():
     return mod
 
 
+def reference_on_headline(ei_t, ptr_t, m_total, k, mode, rows, G):
+    """The reference C++ itself (oracle/_ref, built in the build container from the reference's own sources) on the headline
+    workload, 1 thread.  Single graph: handle API, rows [0, rows) of the job (its preprocessing allocates a visited array per
+    root, reference src/preproc.cpp:202: about half a minute at |V| = 1M, not timed).  Batch: sample_batch, warm LRU."""
+    ref = load_prebuilt_reference()
+    if ref is None:
+        return None
+    if G == 1:
+        t = time.perf_counter()
+        h = ref.create_preproc(ei_t, int(ptr_t[-1]), k)
+        tp = time.perf_counter() - t
+        t = time.perf_counter()
+        ref.sample(h, rows, k, EDGE_MODE[mode], 0, 42)
+        ts = time.perf_counter() - t
+        ref.destroy_preproc(h)
+        desc = f"rows [0,{rows}) of the same job through the reference's handle API (create_preproc {tp:.1f}s excluded), seed 42"
+    else:
+        ref.sample_batch(ei_t, ptr_t, 1, k, mode, 42)
+        m_cpu = max(1, rows // G) if rows < m_total * G else m_total
+        ts = 1e9
+        for _ in range(3):
+            t = time.perf_counter()
+            ref.sample_batch(ei_t, ptr_t, m_cpu, k, mode, 42)
+            ts = min(ts, time.perf_counter() - t)
+        rows = m_cpu * G
+        desc = f"the same {G}-graph batch with m_per_graph={m_cpu} ({rows} rows), best of 3, warm preprocessing LRU"
+    return {"value": round(rows / ts, 1), "unit": "k-subgraphs/s", "cores": 1, "kind": "reference", "cpu_model": cpu_model(),
+            "sample": desc + "; oracle/_ref = the reference's own C++ sources compiled as they are"}
+
+
 def port_vs_reference_on_er_proxy(wl, torch):
     """ER proxy small enough for the reference's O(n^2) preprocessing (n = 100k, same degree law as C5): k-subgraphs/s of
     the reference C++ and of the oracle port on the same rows -- how conservative the `port` CPU baseline is."""
@@ -460,7 +738,9 @@ def port_vs_reference_on_er_proxy(wl, torch):
     t_port = time.perf_counter() - t
     same = bool(all(np.array_equal(a.numpy(), b) for a, b in zip(r, o)))
     return {"graph": "ER n=100k, 2M columns, k=8, 20000 rows", "reference_cpp_subgraphs_per_s": round(m / t_ref, 1),
-            "port_subgraphs_per_s": round(m / t_port, 1), "port_over_reference": round(t_ref / t_port, 3), "identical_output": same}
+            "port_subgraphs_per_s": round(m / t_port, 1), "port_over_reference": round(t_ref / t_port, 3), "identical_output": same,
+            "cpu_baseline": {"value": round(m / t_ref, 1), "unit": "k-subgraphs/s", "cores": 1, "kind": "reference",
+                             "sample": "rows [0,20000) on the ER proxy (same degree law as the headline graph), reference's handle API, preprocessing excluded"}}
 
 
 if __name__ == "__main__":

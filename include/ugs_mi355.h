@@ -128,6 +128,11 @@ int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
 int ugs_plan_fill(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int64_t row_begin,
                   int64_t row_count, void *stream, const int64_t *d_nodes, const int64_t *d_edge_ptr,
                   int64_t *d_edge_index, int64_t ld, int64_t *d_edge_src);
+/* Share (1..100 percent, default 100) of the blocks a CU can hold that this plan's walk kernels occupy.  The walk kernels are
+ * persistent grids that keep every CU's registers, LDS and wave slots to their end; a job that runs other kernels BESIDE a walk
+ * (the collation of the previous batch and its RCCL transfer on another stream) lowers the share so that those find room on
+ * every CU instead of queueing behind the walk. */
+int ugs_plan_set_walk_share(ugs_plan *plan, int percent);
 /* A whole step (seed upload, walk tiers, scan, fill) of a plan captured ONCE as a HIP graph and replayed with a new seed:
  * for batches of small graphs a step is a handful of launches for tens of microseconds of work, and the graph removes the
  * per-launch gaps.  The buffers are the caller's (d_edge_index[2, ld], d_edge_src[ld]: ld >= the largest total it expects;

@@ -131,7 +131,7 @@ static constexpr int UGS_TIER_CAP[UGS_LDS_TIERS] = {64, 448, 1024, 2048};
 static constexpr int UGS_TIER_LANES[UGS_LDS_TIERS] = {8, 64, 64, 64};             // lanes per walk
 static constexpr int UGS_TIER_HASH_LIMIT[UGS_LDS_TIERS] = {96, 448, 1536, 3072};  // TierCfg<CAP>::HLIMIT (static_assert in ugs_kernels.hip)
 
-hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int device_cus, hipStream_t s, UgsLaunchInfo *info);
+hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int device_cus, int share_percent, hipStream_t s, UgsLaunchInfo *info);
 hipError_t ugs_launch_build_prow(const UgsPlanDev &plan, int64_t num_vertices, int2 *prow, int shift, int device_cus, hipStream_t s);
 #define UGS_COLLATE_MAX_WORLD 64
 hipError_t ugs_launch_collate_unpack(const void *d_msgs, int world, int64_t msg_bytes, const int64_t *row_off, int k, int node_b, int eidx_b,

@@ -442,6 +442,7 @@ struct ugs_plan {
     bool last_valid = false;
     PoolBuf prow;                         // padded rows (ugs_device.h), built on the device by the first walk in a one-walk-per-wave tier
     bool prow_pooled = false, prow_failed = false;
+    int walk_share = 100;                 // ugs_plan_set_walk_share
     bool stg_valid = false;
     const void *stg_nodes = nullptr;
     int64_t stg_row_begin = 0, stg_row_count = 0;
@@ -1090,7 +1091,7 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
     }
     a.work_next = dyn ? static_cast<unsigned long long *>(plan->work.p) + 0 : nullptr;
     HIP_TRY(ev_begin(plan, 0, s));
-    HIP_TRY(ugs_launch_walk(a, tc.first, plan->cus, s, &plan->last_walk));
+    HIP_TRY(ugs_launch_walk(a, tc.first, plan->cus, plan->walk_share, s, &plan->last_walk));
     HIP_TRY(ev_end(plan, s));
     HIP_TRY(ev_begin(plan, 1, s));
     int last = 0;   // index of the counter holding rows that nobody processed
@@ -1098,7 +1099,7 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
         a.in_list = static_cast<const int64_t *>(plan->ovf1.p); a.in_count = cnt + 0;
         a.ovf_list = static_cast<int64_t *>(plan->ovf2.p); a.ovf_count = cnt + 1;
         a.work_next = dyn ? static_cast<unsigned long long *>(plan->work.p) + 1 : nullptr;
-        HIP_TRY(ugs_launch_walk(a, tc.second, plan->cus, s, nullptr));
+        HIP_TRY(ugs_launch_walk(a, tc.second, plan->cus, plan->walk_share, s, nullptr));
         last = 1;
     }
     if (tc.third_G) {
@@ -1125,7 +1126,7 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
         a.gws_words_per_group = plan->gws_words; a.gws_groups = plan->gws_groups;
         a.gcap = plan->gcap; a.ghs = plan->ghs; a.gbcap = plan->gbcap; a.gpcap = plan->gpcap;
         a.work_next = nullptr;              // the global tier keeps one walk per workspace slice, static
-        HIP_TRY(ugs_launch_walk(a, UGS_TIER_G, plan->cus, s, nullptr));
+        HIP_TRY(ugs_launch_walk(a, UGS_TIER_G, plan->cus, plan->walk_share, s, nullptr));
         last = 2;
     }
     HIP_TRY(ugs_launch_scan(static_cast<const uint32_t *>(plan->counts.p), row_count, d_edge_ptr, static_cast<int64_t *>(plan->scantmp.p), s));
@@ -1217,6 +1218,7 @@ int ugs_plan_graph_create(ugs_plan *plan, int m_per_graph, int k, int mode, int6
     sh->device = plan->device; sh->cus = plan->cus; sh->G = plan->G; sh->nverts = plan->nverts; sh->nnz = plan->nnz;
     sh->dev = plan->dev;             // device arrays shared, not owned (blob stays null)
     sh->g_n = plan->g_n; sh->g_maxdeg = plan->g_maxdeg; sh->g_sbdeg = plan->g_sbdeg; sh->g_level = plan->g_level;
+    sh->walk_share = plan->walk_share;
     g->shadow = sh;
     auto bail = [&](int rc) { ugs_plan_graph_destroy(g); return rc; };
     hipError_t e = hipStreamCreateWithFlags(&g->cs, hipStreamNonBlocking);
@@ -1291,6 +1293,13 @@ int ugs_collate_unpack(const void *d_msgs, int world, const int64_t *row_off, in
         if (row_off[r + 1] < row_off[r] || row_off[r + 1] - row_off[r] > rows_cap) return fail(UGS_E_BAD_ARG, "collate: a rank's row range exceeds rows_cap");
     HIP_TRY(ugs_launch_collate_unpack(d_msgs, world, mb, row_off, k, node_bytes, eidx_bytes, esrc_bytes, rows_cap, edge_cap, so, d_nodes,
                                       d_edge_index, ld, d_edge_ptr, d_edge_src, static_cast<hipStream_t>(stream)));
+    return UGS_OK;
+}
+
+int ugs_plan_set_walk_share(ugs_plan *plan, int percent) {
+    if (!plan || percent < 1 || percent > 100) return fail(UGS_E_BAD_ARG, "walk share: a plan and 1..100 percent");
+    std::lock_guard<std::mutex> lk(plan->mu);
+    plan->walk_share = percent;
     return UGS_OK;
 }
 

@@ -1424,16 +1424,19 @@ static hipError_t launch_lds(const UgsWalkArgs &a, int cus, int blocks_per_cu, h
 #ifndef UGS_BLOCKS_M
 #define UGS_BLOCKS_M 20
 #endif
-hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, hipStream_t s, UgsLaunchInfo *info) {
+hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, int share_percent, hipStream_t s, UgsLaunchInfo *info) {
     if (cus <= 0) cus = 256;
+    // share_percent < 100: the persistent grid takes only that share of the blocks a CU can hold, so that other kernels (the
+    // collation, RCCL) find registers, LDS and wave slots on every CU while a walk is running (a full grid holds them to its end)
+    auto part = [&](int blocks) { const int b = (int)((long long)blocks * (share_percent <= 0 || share_percent > 100 ? 100 : share_percent) / 100); return b < 1 ? 1 : b; };
     switch (tier) {
-    case UGS_TIER_S: return launch_lds<8, 64, 256>(a, cus, 2, s, info, "ugs_walk_lds<8,64>");
+    case UGS_TIER_S: return launch_lds<8, 64, 256>(a, cus, part(2), s, info, "ugs_walk_lds<8,64>");
     // one walk per wave: two walks per wave (GS 32) measured 26.4 ms vs 18.7 ms per 1M walks on C5 (two chunks per row)
     // resident one-wave blocks per CU: LDS is granted in 1280-byte granules (128 per CU) -- 7648 B = 6 granules -> 21 blocks, of
     // which the register budget (96 VGPRs: 5 waves per SIMD) admits 20; 19.5 KB = 16 granules -> 8; 38.9 KB = 31 granules -> 4
-    case UGS_TIER_M: return launch_lds<64, 448, 64>(a, cus, UGS_BLOCKS_M, s, info, "ugs_walk_lds<64,448>");
-    case UGS_TIER_X: return launch_lds<64, 1024, 64>(a, cus, 8, s, info, "ugs_walk_lds<64,1024>");
-    case UGS_TIER_L: return launch_lds<64, 2048, 64>(a, cus, 4, s, info, "ugs_walk_lds<64,2048>");
+    case UGS_TIER_M: return launch_lds<64, 448, 64>(a, cus, part(UGS_BLOCKS_M), s, info, "ugs_walk_lds<64,448>");
+    case UGS_TIER_X: return launch_lds<64, 1024, 64>(a, cus, part(8), s, info, "ugs_walk_lds<64,1024>");
+    case UGS_TIER_L: return launch_lds<64, 2048, 64>(a, cus, part(4), s, info, "ugs_walk_lds<64,2048>");
     default: {
         int64_t grid = a.gws_words_per_group > 0 ? a.gws_groups : 0;
         if (grid < 1) return hipErrorInvalidValue;

@@ -304,6 +304,11 @@ class Plan:
         check(lib.ugs_plan_last_launch(self._h, name, 128, C.byref(grid), C.byref(block), C.byref(lds), C.byref(ovf)))
         return {"kernel": name.value.decode(), "grid": grid.value, "block": block.value, "lds_bytes": lds.value, "overflow_rows": ovf.value}
 
+    def set_walk_share(self, percent):
+        """Let the walk kernels occupy only `percent` of every CU's resident-block capacity, so that kernels on other streams (the
+        collation of the previous batch, RCCL) run beside a walk instead of behind it."""
+        check(lib.ugs_plan_set_walk_share(self._h, int(percent)))
+
     def set_timing(self, on=True):
         check(lib.ugs_plan_set_timing(self._h, 1 if on else 0))
 
