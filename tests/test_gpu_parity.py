@@ -234,47 +234,85 @@ def test_sharded_path_over_rccl_single_rank():
         dist.destroy_process_group()
 
 
-def test_full_size_properties_er_proxy_and_c4():
-    """Size-independent properties at sizes the CPU oracle would take minutes for: every emitted edge is a column of the
-    input joining two sampled vertices of its row (edge_src consistency, both modes of numbering), rows are growth-ordered
-    and duplicate-free, edge_ptr is the exclusive scan of per-row counts, repeated calls are identical (idempotence), and
-    disjoint row shards concatenate to the unsharded result (digest of digests)."""
+def _check_size_independent_properties(plan, ei_t, m, k, G):
+    """Every emitted edge is a column of the input joining two sampled vertices of its row (edge_src consistency), rows are
+    growth-ordered and duplicate-free, edge_ptr is the exclusive scan of per-row counts, repeated calls are identical
+    (idempotence), and disjoint row shards concatenate to the unsharded result (digest of digests)."""
     import hashlib
+    import torch
+    rows = G * m
+    full = plan.sample_rows(m, mode="global", seed=42)
+    again = plan.sample_rows(m, mode="global", seed=42)
+    assert all(torch.equal(a, b) for a, b in zip(full, again))
+    nodes, eidx, eptr, esrc = full
+    assert int(eptr[0]) == 0 and int(eptr[-1]) == eidx.size(1) == esrc.numel() and bool((eptr[1:] >= eptr[:-1]).all())
+    # rows: distinct vertices (complete rows), -1 only as a suffix
+    valid = nodes >= 0
+    assert bool((valid[:, 1:] <= valid[:, :-1]).all())
+    srt = torch.sort(torch.where(valid, nodes, torch.arange(-k, 0, device=nodes.device).expand_as(nodes)), dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())
+    # edges: endpoints are the column's endpoints (either orientation) and both belong to the row
+    cols = ei_t.cuda()[:, esrc]
+    same = (cols[0] == eidx[0]) & (cols[1] == eidx[1])
+    flip = (cols[0] == eidx[1]) & (cols[1] == eidx[0])
+    assert bool((same | flip).all())
+    row_of_edge = torch.repeat_interleave(torch.arange(rows, device=nodes.device), eptr[1:] - eptr[:-1])
+    assert bool((nodes[row_of_edge] == eidx[0].unsqueeze(1)).any(1).all()) and bool((nodes[row_of_edge] == eidx[1].unsqueeze(1)).any(1).all())
+    # incomplete rows carry no edges
+    assert bool(((eptr[1:] - eptr[:-1])[~valid.all(1)] == 0).all())
+    # shards
+    cuts = [0, rows // 3, rows // 3 + 1, rows]
+    parts = [plan.sample_rows(m, mode="global", seed=42, row_begin=a, row_count=b - a) for a, b in zip(cuts[:-1], cuts[1:])]
+    h = lambda t: hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()
+    assert h(torch.cat([p[0] for p in parts])) == h(nodes) and h(torch.cat([p[1] for p in parts], dim=1)) == h(eidx)
+    assert h(torch.cat([p[3] for p in parts])) == h(esrc)
+    return full
+
+
+def test_full_size_properties_er_proxy_and_c4():
+    """Size-independent properties at sizes the CPU oracle would take minutes for."""
     import torch
     import ugs_sampler
     import ugs_workloads as wl
-    for name, m_override in (("er_200000_4000000_300000_8", None), ("c4_qm9_b65536", None)):
+    for name in ("er_200000_4000000_300000_8", "c4_qm9_b65536"):
         ei, ptr, m, k = wl.workload(name)
         ei_t, ptr_t = torch.from_numpy(ei), torch.from_numpy(ptr)
-        G = len(ptr) - 1
         plan = ugs_sampler.Plan.from_batch(ei_t, ptr_t, k)
-        rows = G * m
-        full = plan.sample_rows(m, mode="global", seed=42)
-        again = plan.sample_rows(m, mode="global", seed=42)
-        assert all(torch.equal(a, b) for a, b in zip(full, again))
-        nodes, eidx, eptr, esrc = full
-        assert int(eptr[0]) == 0 and int(eptr[-1]) == eidx.size(1) == esrc.numel() and bool((eptr[1:] >= eptr[:-1]).all())
-        # rows: distinct vertices (complete rows), -1 only as a suffix
-        valid = nodes >= 0
-        assert bool((valid[:, 1:] <= valid[:, :-1]).all())
-        srt = torch.sort(torch.where(valid, nodes, torch.arange(-k, 0, device=nodes.device).expand_as(nodes)), dim=1).values
-        assert bool((srt[:, 1:] != srt[:, :-1]).all())
-        # edges: endpoints are the column's endpoints (either orientation) and both belong to the row
-        cols = ei_t.cuda()[:, esrc]
-        same = (cols[0] == eidx[0]) & (cols[1] == eidx[1])
-        flip = (cols[0] == eidx[1]) & (cols[1] == eidx[0])
-        assert bool((same | flip).all())
-        row_of_edge = torch.repeat_interleave(torch.arange(rows, device=nodes.device), eptr[1:] - eptr[:-1])
-        assert bool((nodes[row_of_edge] == eidx[0].unsqueeze(1)).any(1).all()) and bool((nodes[row_of_edge] == eidx[1].unsqueeze(1)).any(1).all())
-        # incomplete rows carry no edges
-        assert bool(((eptr[1:] - eptr[:-1])[~valid.all(1)] == 0).all())
-        # shards
-        cuts = [0, rows // 3, rows // 3 + 1, rows]
-        parts = [plan.sample_rows(m, mode="global", seed=42, row_begin=a, row_count=b - a) for a, b in zip(cuts[:-1], cuts[1:])]
-        h = lambda t: hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()
-        assert h(torch.cat([p[0] for p in parts])) == h(nodes) and h(torch.cat([p[1] for p in parts], dim=1)) == h(eidx)
-        assert h(torch.cat([p[3] for p in parts])) == h(esrc)
+        _check_size_independent_properties(plan, ei_t, m, k, len(ptr) - 1)
         plan.close()
+
+
+@pytest.mark.timeout(400)
+def test_c5_headline_job_at_full_size():
+    """BASELINE.json configs[4] itself -- |V| = 1M, 20M columns, k = 8, batch = 1M rows -- through the plan API: the
+    size-independent properties of the whole batch, and ALL FOUR tensors of two row sub-ranges (the first rows and a range in
+    the middle of the batch, both numbering modes) bit for bit against the CPU oracle."""
+    import torch
+    import oracle
+    import ugs_sampler
+    import ugs_workloads as wl
+    ei, ptr, m, k = wl.workload("c5_er_1m")
+    assert (m, k, int(ptr[-1])) == (1_000_000, 8, 1_000_000) and ei.shape[1] > 19_990_000
+    ei_t, ptr_t = torch.from_numpy(ei), torch.from_numpy(ptr)
+    plan = ugs_sampler.Plan.from_batch(ei_t, ptr_t, k)
+    assert plan.info()["tier"] == 1                                            # the 448-candidate one-walk-per-wave tier
+    full = _check_size_independent_properties(plan, ei_t, m, k, 1)
+    nodes, eidx, eptr, esrc = [t.cpu().numpy() for t in full]
+    assert nodes.shape == (m, k) and (nodes >= 0).all()                        # every row complete on this graph
+    P = oracle.Preproc(ei, 1_000_000, k)
+    for lo, n in ((0, 12_000), (777_777, 4_000)):
+        w_nodes, w_eidx, w_eptr, w_esrc = P.sample(m, k, "global", 0, 42, lo, lo + n)
+        e0, e1 = int(eptr[lo]), int(eptr[lo + n])
+        assert np.array_equal(nodes[lo:lo + n], w_nodes) and np.array_equal(eptr[lo:lo + n + 1] - e0, w_eptr)
+        assert np.array_equal(eidx[:, e0:e1], w_eidx) and np.array_equal(esrc[e0:e1], w_esrc)
+    # the numbering of sample_batch's default mode on a shard of the same job
+    lo, n = 400_000, 3_000
+    g = [t.cpu().numpy() for t in plan.sample_rows(m, mode="sample", seed=42, row_begin=lo, row_count=n)]
+    w = P.sample(m, k, "local", 0, 42, lo, lo + n)
+    for a, b in zip(g, w):
+        assert np.array_equal(a, b)
+    P.close()
+    plan.close()
 
 
 def test_more_edge_cases_vs_oracle(product, orc):
