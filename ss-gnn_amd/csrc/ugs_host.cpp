@@ -687,6 +687,59 @@ void plan_cache_clear() {
     for (auto *v : victims) plan_unref(v);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Repeated batches.  The reference interface hands the whole batch over on every call, and the reference (like the general
+// path below) walks every column of it to slice, renumber and hash the graphs before it finds its preprocessing in the LRU.
+// A training loop calls with the SAME batch tensors again and again (gps/experiment.py:882-883, fixed seed), so calls are
+// first matched as a whole: a 128-bit content hash of (edge_index rows, ptr) -- two independent 64-bit multiply-fold lanes
+// over every byte, one pass at memory speed -- names the batch; a hit replays exactly what the general path would do to the
+// LRU (one lookup per graph, in graph order: same recency order, same hit counters) and, if every graph is still cached under
+// the same handle and the plan is still in the plan cache, returns that plan.  Anything else falls through to the general
+// path.  Observable behaviour is that of the general path; the cost drops from several passes over the columns with
+// per-column searches and copies (0.24 s per call on the 20M-column graph) to one hashing pass.
+// ---------------------------------------------------------------------------------------------------------------
+struct Hash128 { uint64_t a, b; bool operator==(const Hash128 &o) const { return a == o.a && b == o.b; } };
+inline uint64_t mum(uint64_t x, uint64_t y) { const __uint128_t r = (__uint128_t)x * y; return (uint64_t)r ^ (uint64_t)(r >> 64); }
+void hash_words(const int64_t *p, int64_t n, Hash128 &h) {
+    const uint64_t K0 = 0xa0761d6478bd642full, K1 = 0xe7037ed1a0b428dbull, K2 = 0x8ebc6af09c88c6e3ull, K3 = 0x589965cc75374cc3ull;
+    uint64_t a0 = h.a, a1 = h.a ^ K2, b0 = h.b, b1 = h.b ^ K3;
+    int64_t i = 0;
+    for (; i + 4 <= n; i += 4) {      // two accumulators per lane: the multiplies of consecutive groups overlap
+        const uint64_t x0 = (uint64_t)p[i], x1 = (uint64_t)p[i + 1], x2 = (uint64_t)p[i + 2], x3 = (uint64_t)p[i + 3];
+        a0 = mum(x0 ^ K0, x1 ^ a0); a1 = mum(x2 ^ K0, x3 ^ a1);
+        b0 = mum(x1 ^ K1, x0 ^ b0); b1 = mum(x3 ^ K1, x2 ^ b1);
+    }
+    for (; i < n; ++i) { a0 = mum((uint64_t)p[i] ^ K0, a0 ^ K2); b0 = mum((uint64_t)p[i] ^ K1, b0 ^ K3); }
+    h.a = mum(a0 ^ K1, a1 ^ (uint64_t)n); h.b = mum(b0 ^ K0, b1 ^ (uint64_t)n);
+}
+struct BatchEntry {
+    Hash128 h; int64_t E, G; int k, dev;
+    uint64_t plan_key;
+    std::vector<std::pair<uint64_t, int64_t>> graphs;     // (LRU key, handle) of every non-degenerate graph, in graph order
+};
+std::mutex g_bi_mu;
+std::list<BatchEntry> &g_batch_index = *new std::list<BatchEntry>();   // front = most recent, at most as many as cached plans
+void batch_index_clear() { std::lock_guard<std::mutex> lk(g_bi_mu); g_batch_index.clear(); }
+
+Hash128 batch_hash(const int64_t *src, const int64_t *dst, int64_t E, const int64_t *ptr, int64_t G) {
+    Hash128 h{0x2d358dccaa6c78a5ull ^ (uint64_t)E, 0x8bb84b93962eacc9ull ^ (uint64_t)G};
+    hash_words(ptr, G + 1, h);
+    hash_words(src, E, h);
+    hash_words(dst, E, h);
+    return h;
+}
+
+// the LRU touches of a matched batch; false = some graph is no longer cached under the recorded handle (caller takes the general path)
+bool batch_replay(const BatchEntry &e, int64_t &hits) {
+    std::lock_guard<std::mutex> lk(g_lru_mu);
+    for (auto &kh : e.graphs) {
+        int64_t handle = 0;
+        if (!lru().get(kh.first, handle) || handle != kh.second) return false;
+        ++lru().hits; ++hits;
+    }
+    return true;
+}
+
 // pick the walk tier(s) for k: the candidate set of a walk holds at most min(n-1, (k-1)*max degree) vertices
 TierChoice choose_tier(ugs_plan *p, int k) {
     std::lock_guard<std::mutex> lk(p->mu);
@@ -905,6 +958,7 @@ int ugs_cache_clear(void) {
         c.items.clear(); c.index.clear(); c.hits = c.misses = 0;
     }
     plan_cache_clear();
+    batch_index_clear();
     return UGS_OK;
 }
 
@@ -944,12 +998,46 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
     if (int rc = device_ctx(dc)) return rc;
     const int64_t G = num_graphs, E = num_cols;
     const int64_t *src = edge_index, *dst = edge_index + row_stride;
+    // the batch as a whole: seen before, and everything it needs still cached?
+    const bool use_index = std::getenv("UGS_NO_BATCH_INDEX") == nullptr;
+    Hash128 bh{0, 0};
+    if (use_index) {
+        bh = batch_hash(src, dst, E, ptr, G);
+        BatchEntry found;
+        bool have = false;
+        {
+            std::lock_guard<std::mutex> lk(g_bi_mu);
+            for (auto it = g_batch_index.begin(); it != g_batch_index.end(); ++it)
+                if (it->h == bh && it->E == E && it->G == G && it->k == k && it->dev == dc.id) {
+                    g_batch_index.splice(g_batch_index.begin(), g_batch_index, it);
+                    found = *it; have = true;
+                    break;
+                }
+        }
+        if (have) {
+            int64_t hits = 0;
+            if (batch_replay(found, hits)) {
+                if (ugs_plan *cached = plan_cache_get(found.plan_key, dc.id)) {
+                    if (debug_on()) {
+                        std::lock_guard<std::mutex> lk(g_lru_mu);
+                        std::fprintf(stderr, "[UGS CACHE] hits=%lld misses=0 cache_size=%zu\n", (long long)hits, lru().items.size());
+                    }
+                    *plan_out = cached;
+                    return UGS_OK;
+                }
+            }
+            // fall through: the general path repeats the lookups (same final recency order); undo the hits counted above
+            std::lock_guard<std::mutex> lk(g_lru_mu);
+            lru().hits -= hits;
+        }
+    }
     std::vector<int64_t> cstart, cols_of;                      // per-graph column lists, concatenated
     Lap lap;
     assign_columns(src, dst, E, ptr, G, cstart, cols_of);
     const double t_assign = lap();
     // --- per graph: renumber, hash, LRU lookup / preprocessing ------------------------------------------------------
     std::vector<PlanPiece> pieces((size_t)G);
+    std::vector<std::pair<uint64_t, int64_t>> touched;          // (LRU key, handle) per non-degenerate graph, for the batch index
     std::vector<int64_t> ru, rv, evicted;
     uint64_t pkey = 14695981039346656037ull;
     const uint64_t prime = 1099511628211ull;
@@ -983,6 +1071,7 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
             ++misses;
         } else ++hits;
         pc.g = gr;
+        touched.emplace_back(key, handle);
         pc.colmap = cols_of.data() + c0;
         pc.ncols = cn;
         mix((uint64_t)handle); mix((uint64_t)cn);
@@ -993,7 +1082,15 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
         std::lock_guard<std::mutex> lk(g_lru_mu);
         std::fprintf(stderr, "[UGS CACHE] hits=%lld misses=%lld cache_size=%zu\n", (long long)hits, (long long)misses, lru().items.size());
     }
-    if (ugs_plan *cached = plan_cache_get(pkey, dc.id)) { *plan_out = cached; return UGS_OK; }
+    auto remember = [&] {
+        if (!use_index) return;
+        std::lock_guard<std::mutex> lk(g_bi_mu);
+        for (auto it = g_batch_index.begin(); it != g_batch_index.end(); ++it)
+            if (it->h == bh && it->E == E && it->G == G && it->k == k && it->dev == dc.id) { g_batch_index.erase(it); break; }
+        g_batch_index.push_front(BatchEntry{bh, E, G, k, dc.id, pkey, std::move(touched)});
+        while (g_batch_index.size() > g_plan_cache_cap) g_batch_index.pop_back();
+    };
+    if (ugs_plan *cached = plan_cache_get(pkey, dc.id)) { remember(); *plan_out = cached; return UGS_OK; }
     const double t_graphs = lap();
     auto *p = new ugs_plan();
     p->cache_key = pkey;
@@ -1001,6 +1098,7 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
     if (debug_on() && E >= ((int64_t)1 << 21))
         std::fprintf(stderr, "[UGS PLAN] columns -> graphs %.3fs, renumber + hash + preprocessing %.3fs, assemble + upload %.3fs\n", t_assign, t_graphs, lap());
     plan_cache_put(p);
+    remember();
     *plan_out = p;
     return UGS_OK;
 }
@@ -1347,7 +1445,8 @@ struct ugs_job {
     int m = 0, k = 0, mode = 0;
     int64_t extra = 0, rows = 0, total = 0, G = 0;
     bool batch = false;
-    PoolBuf nodes, eptr;
+    PoolBuf nodes;                     // nodes [rows, k] and, right behind it, edge_ptr [rows + 1]: one buffer, so that a caller whose
+    int64_t *d_eptr = nullptr;         // output tensors are adjacent too gets both with one copy
     // epsilon_uniform path
     bool eps = false;
     PoolBuf eps_blob;                  // pooled: hipMalloc/hipFree per call cost milliseconds once the process holds large plans
@@ -1358,7 +1457,7 @@ struct ugs_job {
 namespace {
 void free_job(ugs_job *j) {
     if (!j) return;
-    pool_put(j->nodes); pool_put(j->eptr);
+    pool_put(j->nodes);
     pool_put(j->eps_counts); pool_put(j->eps_scantmp);
     pool_put(j->eps_blob);
     plan_unref(j->plan);
@@ -1372,10 +1471,11 @@ int begin_common(ugs_plan *plan, int m, int k, int mode, int64_t extra, int seed
     j->plan = plan; j->dc = dc; j->m = m; j->k = k; j->mode = mode; j->extra = extra; j->batch = batch;
     j->G = plan->G;
     j->rows = plan->G * (int64_t)m;
-    int rc = pool_get((size_t)std::max<int64_t>(j->rows * k, 1) * sizeof(int64_t), dc.id, j->nodes);
-    if (!rc) rc = pool_get((size_t)(j->rows + 1) * sizeof(int64_t), dc.id, j->eptr);
-    if (!rc) rc = ugs_plan_walk(plan, m, k, mode, extra, seed, 0, j->rows, dc.stream, static_cast<int64_t *>(j->nodes.p),
-                                static_cast<int64_t *>(j->eptr.p), &j->total);
+    int rc = pool_get((size_t)(j->rows * k + j->rows + 1) * sizeof(int64_t), dc.id, j->nodes);
+    if (!rc) {
+        j->d_eptr = static_cast<int64_t *>(j->nodes.p) + j->rows * k;
+        rc = ugs_plan_walk(plan, m, k, mode, extra, seed, 0, j->rows, dc.stream, static_cast<int64_t *>(j->nodes.p), j->d_eptr, &j->total);
+    }
     if (rc) { free_job(j); return rc; }
     *job_out = j;
     if (total_out) *total_out = j->total;
@@ -1386,31 +1486,39 @@ int finish_common(ugs_job *j, int64_t *nodes, int64_t *edge_index, int64_t *edge
     hipStream_t s = j->dc.stream;
     const int64_t rows = j->rows, k = j->k, tot = j->total;
     int rc = UGS_OK;
-    PoolBuf e_idx, e_src;
+    PoolBuf e_idx;                     // host outputs: edge_index [2, tot] and edge_src [tot] staged in ONE device buffer
     auto body = [&]() -> int {
         HIP_TRY(hipSetDevice(j->dc.id));
         int64_t *d_ei = edge_index, *d_es = edge_src;
         if (!dst_is_device && tot > 0) {
-            if (int r = pool_get((size_t)(2 * tot) * sizeof(int64_t), j->dc.id, e_idx)) return r;
-            if (int r = pool_get((size_t)tot * sizeof(int64_t), j->dc.id, e_src)) return r;
-            d_ei = static_cast<int64_t *>(e_idx.p); d_es = static_cast<int64_t *>(e_src.p);
+            if (int r = pool_get((size_t)(3 * tot) * sizeof(int64_t), j->dc.id, e_idx)) return r;
+            d_ei = static_cast<int64_t *>(e_idx.p); d_es = d_ei + 2 * tot;
         }
         if (tot > 0 && j->eps) {
             if (!d_ei || !d_es) return fail(UGS_E_BAD_ARG, "null edge output pointer");
             UgsEpsLaunch l = j->eps_l;
-            l.edge_ptr = static_cast<const int64_t *>(j->eptr.p); l.edge_index = d_ei; l.edge_src = d_es; l.ld = tot;
+            l.edge_ptr = j->d_eptr; l.edge_index = d_ei; l.edge_src = d_es; l.ld = tot;
             HIP_TRY(ugs_eps_launch(l, 1, j->dc.cus, s));
         } else if (tot > 0) {
             if (!d_ei || !d_es) return fail(UGS_E_BAD_ARG, "null edge output pointer");
             if (int r = ugs_plan_fill(j->plan, j->m, j->k, j->mode, j->extra, 0, rows, s, static_cast<const int64_t *>(j->nodes.p),
-                                      static_cast<const int64_t *>(j->eptr.p), d_ei, tot, d_es)) return r;
+                                      j->d_eptr, d_ei, tot, d_es)) return r;
         }
         const hipMemcpyKind kind = dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-        if (rows * k > 0) HIP_TRY(hipMemcpyAsync(nodes, j->nodes.p, (size_t)(rows * k) * sizeof(int64_t), kind, s));
-        HIP_TRY(hipMemcpyAsync(edge_ptr, j->eptr.p, (size_t)(rows + 1) * sizeof(int64_t), kind, s));
+        // adjacent outputs (the Python shim carves its tensors out of one allocation) travel in one copy each
+        if (edge_ptr == nodes + rows * k) {
+            HIP_TRY(hipMemcpyAsync(nodes, j->nodes.p, (size_t)(rows * k + rows + 1) * sizeof(int64_t), kind, s));
+        } else {
+            if (rows * k > 0) HIP_TRY(hipMemcpyAsync(nodes, j->nodes.p, (size_t)(rows * k) * sizeof(int64_t), kind, s));
+            HIP_TRY(hipMemcpyAsync(edge_ptr, j->d_eptr, (size_t)(rows + 1) * sizeof(int64_t), kind, s));
+        }
         if (!dst_is_device && tot > 0) {
-            HIP_TRY(hipMemcpyAsync(edge_index, d_ei, (size_t)(2 * tot) * sizeof(int64_t), kind, s));
-            HIP_TRY(hipMemcpyAsync(edge_src, d_es, (size_t)tot * sizeof(int64_t), kind, s));
+            if (edge_src == edge_index + 2 * tot) {
+                HIP_TRY(hipMemcpyAsync(edge_index, d_ei, (size_t)(3 * tot) * sizeof(int64_t), kind, s));
+            } else {
+                HIP_TRY(hipMemcpyAsync(edge_index, d_ei, (size_t)(2 * tot) * sizeof(int64_t), kind, s));
+                HIP_TRY(hipMemcpyAsync(edge_src, d_es, (size_t)tot * sizeof(int64_t), kind, s));
+            }
         }
         if (sample_ptr) {
             std::vector<int64_t> sp((size_t)j->G + 1);
@@ -1422,7 +1530,7 @@ int finish_common(ugs_job *j, int64_t *nodes, int64_t *edge_index, int64_t *edge
         return UGS_OK;
     };
     rc = body();
-    pool_put(e_idx); pool_put(e_src);
+    pool_put(e_idx);
     free_job(j);
     return rc;
 }
@@ -1524,8 +1632,8 @@ int ugs_eps_sample_batch_begin(const int64_t *edge_index, int64_t row_stride, in
     hipError_t e = hipMemcpy(j->eps_blob.p, host.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) return bail(fail_hip(e, "hipMemcpy"));
     char *base = static_cast<char *>(j->eps_blob.p);
-    if (int rc = pool_get((size_t)std::max<int64_t>(j->rows * k, 1) * sizeof(int64_t), dc.id, j->nodes)) return bail(rc);
-    if (int rc = pool_get((size_t)(j->rows + 1) * sizeof(int64_t), dc.id, j->eptr)) return bail(rc);
+    if (int rc = pool_get((size_t)(j->rows * k + j->rows + 1) * sizeof(int64_t), dc.id, j->nodes)) return bail(rc);
+    j->d_eptr = static_cast<int64_t *>(j->nodes.p) + j->rows * k;
     if (int rc = pool_get((size_t)std::max<int64_t>(j->rows, 1) * sizeof(uint32_t), dc.id, j->eps_counts)) return bail(rc);
     if (int rc = pool_get((size_t)ugs_scan_tmp_words(j->rows) * sizeof(int64_t), dc.id, j->eps_scantmp)) return bail(rc);
     UgsEpsLaunch &l = j->eps_l;
@@ -1540,9 +1648,9 @@ int ugs_eps_sample_batch_begin(const int64_t *edge_index, int64_t row_stride, in
     l.edge_ptr = nullptr; l.edge_index = nullptr; l.edge_src = nullptr; l.ld = 0;
     e = ugs_eps_launch(l, 0, dc.cus, dc.stream);
     if (e != hipSuccess) return bail(fail_hip(e, "ugs_eps_walk"));
-    e = ugs_launch_scan(l.counts, j->rows, static_cast<int64_t *>(j->eptr.p), static_cast<int64_t *>(j->eps_scantmp.p), dc.stream);
+    e = ugs_launch_scan(l.counts, j->rows, j->d_eptr, static_cast<int64_t *>(j->eps_scantmp.p), dc.stream);
     if (e != hipSuccess) return bail(fail_hip(e, "ugs_launch_scan"));
-    e = hipMemcpyAsync(&j->total, static_cast<int64_t *>(j->eptr.p) + j->rows, sizeof(int64_t), hipMemcpyDeviceToHost, dc.stream);
+    e = hipMemcpyAsync(&j->total, j->d_eptr + j->rows, sizeof(int64_t), hipMemcpyDeviceToHost, dc.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(dc.stream);
     if (e != hipSuccess) return bail(fail_hip(e, "epsilon walk"));
     *job_out = j;

@@ -67,6 +67,18 @@ def _out_opts(device):
     return dict(dtype=torch.int64, device=dev), 1
 
 
+def _carve(opts, shapes):
+    """int64 tensors of the given shapes as views of ONE allocation, in order: one allocator call instead of len(shapes), and
+    the library moves adjacent outputs with one copy (ugs_host.cpp finish_common).  Each view is contiguous."""
+    sizes = [int(torch.Size(s).numel()) for s in shapes]
+    buf = torch.empty((sum(sizes),), **opts)
+    out, off = [], 0
+    for s, n in zip(shapes, sizes):
+        out.append(buf[off:off + n].view(s))
+        off += n
+    return out
+
+
 def device_count():
     n = C.c_int()
     check(lib.ugs_device_count(C.byref(n)))
@@ -150,10 +162,7 @@ def sample(handle, m_per_graph, k, edge_mode="local", base_offset=0, seed=42, *,
     check(lib.ugs_sample_begin(int(handle), m, k, _EDGE_MODES[edge_mode], int(base_offset), seed, C.byref(job), C.byref(total)))
     try:
         opts, on_dev = _out_opts(device)
-        nodes = torch.empty((m, k), **opts)
-        edge_index = torch.empty((2, total.value), **opts)
-        edge_ptr = torch.empty((m + 1,), **opts)
-        edge_src = torch.empty((total.value,), **opts)
+        nodes, edge_ptr, edge_index, edge_src = _carve(opts, [(m, k), (m + 1,), (2, total.value), (total.value,)])
     except BaseException:
         lib.ugs_job_cancel(job)
         raise
@@ -183,11 +192,7 @@ def sample_batch(edge_index, ptr, m_per_graph, k, mode="sample", seed=42, *, dev
     try:
         opts, on_dev = _out_opts(device)
         B = max(G, 0) * m
-        nodes = torch.empty((B, k), **opts)
-        edge_index_t = torch.empty((2, total.value), **opts)
-        edge_ptr = torch.empty((B + 1,), **opts)
-        sample_ptr = torch.empty((max(G, 0) + 1,), **opts)
-        edge_src = torch.empty((total.value,), **opts)
+        nodes, edge_ptr, edge_index_t, edge_src, sample_ptr = _carve(opts, [(B, k), (B + 1,), (2, total.value), (total.value,), (max(G, 0) + 1,)])
     except BaseException:
         lib.ugs_job_cancel(job)
         raise
