@@ -731,18 +731,18 @@ struct StageCtx {
 };
 
 template <int GS>
-__device__ __forceinline__ void stage_hits(StageCtx &sc, const Grp<GS> &g, bool in_s, uint32_t w, int64_t p, uint32_t size) {
+__device__ __forceinline__ void stage_hits(StageCtx &sc, const Grp<GS> &g, bool in_s, uint32_t w, uint32_t p, uint32_t size) {
     const uint64_t im = g.ballot(in_s);
     if (!im) return;
     const uint32_t slot = sc.ne + (uint32_t)__popcll(im & g.lt_mask());
-    if (in_s && slot < UGS_STAGE_ENTRIES) sc.EL[slot] = make_uint4((uint32_t)p, w, size - 1u, 0u);
+    if (in_s && slot < UGS_STAGE_ENTRIES) sc.EL[slot] = make_uint4(p, w, size - 1u, 0u);
     sc.ne += (uint32_t)__popcll(im);
 }
 
-// One chunk of an adjacency row: lane holds entry e (neighbour, rank) at CSR position p if `valid`.
+// One chunk of an adjacency row: lane holds entry e (neighbour, rank) at CSR position p if `valid` (a plan has < 2^31 entries).
 template <int GS, class SP, bool ADD, bool STG>
 __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g, uint32_t v, uint32_t root_vi, uint32_t size, uint32_t &c,
-                                           uint32_t &hcount, uint32_t &ecount, StageCtx &sc, bool valid, int2 e, int64_t p) {
+                                           uint32_t &hcount, uint32_t &ecount, StageCtx &sc, bool valid, int2 e, uint32_t p) {
     const uint32_t w = valid ? (uint32_t)e.x : 0u;
     const bool cand = valid && (uint32_t)e.y >= root_vi;
     uint32_t slot = hash_slot(w, ws.hmask);
@@ -808,9 +808,9 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
 template <int GS, class SP, bool ADD, bool STG>
 __device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, const UgsPlanDev &P, uint32_t v,
                                          uint32_t root_vi, uint32_t size, uint32_t &c, uint32_t &hcount,
-                                         uint32_t &ecount, int64_t r0, int64_t r1, StageCtx &sc) {
-    for (int64_t base = r0; base < r1; base += GS) {
-        const int64_t p = base + g.lane;
+                                         uint32_t &ecount, uint32_t r0, uint32_t r1, StageCtx &sc) {
+    for (uint32_t base = r0; base < r1; base += GS) {
+        const uint32_t p = base + (uint32_t)g.lane;
         const bool valid = p < r1;
         int2 e = make_int2(0, 0);
         if (valid) e = P.adj[p];
@@ -832,16 +832,16 @@ __device__ __forceinline__ bool scan_prow(const Work<SP> &ws, const Grp<64> &g, 
                                           uint32_t root_vi, uint32_t size, uint32_t &c, uint32_t &hcount,
                                           uint32_t &ecount, int2 e0, int64_t vrow, StageCtx &sc) {
     const uint32_t deg = g.bcast((uint32_t)e0.x, 0);
-    const int64_t start = (int64_t)g.bcast((uint32_t)e0.y, 0);
+    const uint32_t start = g.bcast((uint32_t)e0.y, 0);
     const uint32_t inl = (1u << P.prow_shift) - 1u;                              // entries held by the block itself
     const uint32_t n0 = deg < inl ? deg : inl;
     if (n0 >= (uint32_t)P.prow_first) {                                          // the row reaches into the lines not fetched yet
         if (g.lane >= P.prow_first && g.lane <= (int)n0) e0 = P.prow[(vrow << P.prow_shift) + g.lane];
     }
-    if (n0 && !scan_chunk<64, SP, ADD, STG>(ws, g, v, root_vi, size, c, hcount, ecount, sc, (uint32_t)(g.lane - 1) < n0, e0, start + g.lane - 1)) return false;
-    const int64_t r1 = start + deg;
-    for (int64_t base = start + inl; base < r1; base += 64) {
-        const int64_t p = base + g.lane;
+    if (n0 && !scan_chunk<64, SP, ADD, STG>(ws, g, v, root_vi, size, c, hcount, ecount, sc, (uint32_t)(g.lane - 1) < n0, e0, start + (uint32_t)g.lane - 1u)) return false;
+    const uint32_t r1 = start + deg;
+    for (uint32_t base = start + inl; base < r1; base += 64) {
+        const uint32_t p = base + (uint32_t)g.lane;
         const bool valid = p < r1;
         int2 e = make_int2(0, 0);
         if (valid) e = P.adj[p];
@@ -930,11 +930,11 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
     uint32_t size = 1, c = 0, hcount = 1, ecount = 0;
     int nvalid = 0;           // leading stages of the order computation that are still valid
     STAMP_END(0);
-    int64_t r0 = 0, r1 = 0;
+    uint32_t r0 = 0, r1 = 0;
     int2 e0 = make_int2(0, 0);
     uint32_t v = root_v;                                                      // the vertex whose row is scanned next (local index size-1)
     if constexpr (PAD) e0 = load_prow(P, gd.vbase + v, g.lane);
-    else { r0 = g.uni(P.rowptr[gd.rbase + v]); r1 = g.uni(P.rowptr[gd.rbase + v + 1]); }
+    else { r0 = g.uni((uint32_t)P.rowptr[gd.rbase + v]); r1 = g.uni((uint32_t)P.rowptr[gd.rbase + v + 1]); }
     for (int step = 0;; ++step) {
         bool ok;
         if (step < k - 1) {                                                   // the last vertex adds no candidates
@@ -954,8 +954,8 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
         if constexpr (PAD) {
             e0 = load_prow(P, gd.vbase + w, g.lane);                  // the row itself: issued now, consumed after the candidate list has been updated
         } else {
-            r0 = P.rowptr[gd.rbase + w];
-            r1 = P.rowptr[gd.rbase + w + 1];
+            r0 = (uint32_t)P.rowptr[gd.rbase + w];
+            r1 = (uint32_t)P.rowptr[gd.rbase + w + 1];
             r0 = g.uni(r0); r1 = g.uni(r1);
         }
         STAMP_END(2);
@@ -1085,11 +1085,11 @@ __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP <= 64 ||
     // consecutive items, the first chunk by group index, every further one from a device counter (one round trip per chunk: a
     // single hot address answers in several microseconds); a walk's cost varies, so a static split ends with the unluckiest wave.
     // Two loops, two inlined copies of the walk: one shared loop measured 0.8 % slower on C5 (register allocation).
-#ifndef UGS_WORK_CHUNK
-#define UGS_WORK_CHUNK 4
-#endif
     if (a.work_next) {
-        constexpr int64_t kWorkChunk = UGS_WORK_CHUNK;
+        // chunks of 4 (2 / 4 / 8 / 16 rows per counter round trip measured 8.85 / 8.83 / 8.91 / 9.04 ms per 1M walks; 1 is 50 % slower:
+        // the counter's round trip under contention); launches that give a group only a few dozen walks (a rank's shard of a
+        // strong-scaled batch) end more evenly with 2 (125k walks: 0.985 against 1.006 ms)
+        const int64_t kWorkChunk = total < ngroups * 64 ? 2 : 4;
         int64_t it = ((int64_t)blockIdx.x * GROUPS + gib) * kWorkChunk;
         while (it < total) {
             const int64_t end = it + kWorkChunk < total ? it + kWorkChunk : total;
