@@ -44,6 +44,10 @@ extern "C" {
 #define UGS_MODE_SAMPLE 0
 #define UGS_MODE_GRAPH 1
 #define UGS_MODE_GLOBAL 2
+/* ugs_plan_fill only (no reference counterpart): endpoints numbered r * k + local index, r = row's position inside this call's row range --
+ * the edge index the consumer builds from edge_index_t + repeat_interleave(arange(B), counts) * k
+ * (reference src/gps/gps/models/ss_gnn.py:463-464), so that step (and its host synchronisation) disappears */
+#define UGS_FILL_BATCH 3
 
 const char *ugs_last_error(void);
 const char *ugs_version(void);
@@ -196,6 +200,15 @@ int ugs_eps_sample_batch_finish(ugs_job *job, int64_t *nodes, int64_t *edge_inde
  *      (failed samples are dropped, like the reference). */
 int ugs_apx_sample_batch(const int64_t *edge_index, int64_t row_stride, int64_t num_cols, const int64_t *ptr, int64_t ptr_len,
                          int m_per_graph, int k, uint64_t seed, double epsilon, int64_t *samples_out, int64_t *num_samples_out);
+
+/* GPU variant of the same entry point: the same algorithm with one generator per (sample, trial) -- all samples and thousands of
+ * trials run side by side, a sample's result is its accepted trial with the smallest index (deterministic in (graph, seed)).
+ * Parity with the reference is statistical (same output law), not bit-wise.  2 <= k <= 8.
+ * order_pos_out / est_out (optional, capacity order_capacity >= number of vertices): position of every vertex in the APX-DD order
+ * and its bucket estimate, for the law check of the tests. */
+int ugs_apx_gpu_sample_batch(const int64_t *edge_index, int64_t row_stride, int64_t num_cols, const int64_t *ptr, int64_t ptr_len,
+                             int m_per_graph, int k, uint64_t seed, double epsilon, int64_t *samples_out, int64_t *num_samples_out,
+                             int32_t *order_pos_out, double *est_out, int64_t order_capacity);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (off by default).  get_timing synchronises the
  * recorded events, returns summed milliseconds and launch counts for [0] the first-tier walk kernel, [1] overflow

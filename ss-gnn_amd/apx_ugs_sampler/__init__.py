@@ -16,8 +16,15 @@ from ugs_sampler._lib import check, lib
 __all__ = ["sample_batch"]
 
 
-def sample_batch(edge_index, ptr, m_per_graph, k, mode="sample", seed=42, epsilon=0.1):
-    """APX-UGS epsilon-uniform graphlet sampling"""
+def sample_batch(edge_index, ptr, m_per_graph, k, mode="sample", seed=42, epsilon=0.1, *, backend="host", return_order=False):
+    """APX-UGS epsilon-uniform graphlet sampling
+
+    backend="host" (default): the reference's sequential generator, bit-exact with the reference.
+    backend="gpu": the same algorithm on the GPU, one generator per (sample, trial), all samples and trials side by side; same
+    output law (statistical parity), deterministic in (graph, seed); 2 <= k <= 8.  return_order=True (gpu only) appends the
+    APX-DD order positions and bucket estimates it used (testing aid)."""
+    if backend not in ("host", "gpu"):
+        raise RuntimeError("backend must be 'host' or 'gpu'")
     ei = edge_index.cpu().to(torch.int64)
     if ei.size(1) > 0 and ei.stride(1) != 1:
         ei = ei.contiguous()
@@ -25,6 +32,17 @@ def sample_batch(edge_index, ptr, m_per_graph, k, mode="sample", seed=42, epsilo
     m, k = int(m_per_graph), int(k)
     out = torch.zeros((max(m, 0), k), dtype=torch.int64)
     n = C.c_int64()
+    if backend == "gpu":
+        nv = int(ei[:, max(int(pt[0]), 0):int(pt[1])].max().item()) + 1 if ei.size(1) and int(pt[1]) > int(pt[0]) else 0
+        pos = torch.full((max(nv, 1),), -1, dtype=torch.int32)
+        est = torch.zeros((max(nv, 1),), dtype=torch.float64)
+        check(lib.ugs_apx_gpu_sample_batch(ei.data_ptr(), ei.stride(0) if ei.size(1) else 0, ei.size(1), pt.data_ptr(), pt.numel(), m, k,
+                                           C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_double(float(epsilon)), out.data_ptr(), C.byref(n),
+                                           pos.data_ptr(), est.data_ptr(), pos.numel()))
+        s = n.value
+        res = (out[:s].t().contiguous(), torch.arange(0, s + 1, dtype=torch.int64)) if s else \
+              (torch.zeros((k, 0), dtype=torch.int64), torch.zeros((1,), dtype=torch.int64))
+        return res + (pos[:nv], est[:nv]) if return_order else res
     check(lib.ugs_apx_sample_batch(ei.data_ptr(), ei.stride(0) if ei.size(1) else 0, ei.size(1), pt.data_ptr(), pt.numel(), m, k,
                                    C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_double(float(epsilon)), out.data_ptr(), C.byref(n)))
     s = n.value

@@ -51,6 +51,10 @@ namespace {
 
 thread_local std::string t_err;
 int fail(int code, const std::string &msg) { t_err = msg; return code; }
+}  // namespace
+// the other translation units of the library report through the same thread-local message (internal, not part of the C ABI)
+int ugs_internal_fail(int code, const char *msg) { return fail(code, msg ? msg : ""); }
+namespace {
 int fail_hip(hipError_t e, const char *what) { return fail(UGS_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail_hip(e_, #expr); } while (0)
 
@@ -1250,7 +1254,7 @@ int ugs_plan_fill(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
                   void *stream, const int64_t *d_nodes, const int64_t *d_edge_ptr, int64_t *d_edge_index, int64_t ld, int64_t *d_edge_src) {
     if (!plan) return fail(UGS_E_BAD_ARG, "plan is null");
     if (k < 1 || k > UGS_KMAX) return fail(UGS_E_UNSUPPORTED, "k outside [1, 32]");
-    if (mode < 0 || mode > 2) return fail(UGS_E_BAD_MODE, "mode must be one of: 'sample', 'graph', 'global'");
+    if (mode < 0 || mode > UGS_FILL_BATCH) return fail(UGS_E_BAD_MODE, "mode must be one of: 'sample', 'graph', 'global'");
     if (row_count <= 0) return UGS_OK;
     HIP_TRY(hipSetDevice(plan->device));
     UgsFillArgs a{};

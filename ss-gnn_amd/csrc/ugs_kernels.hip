@@ -1326,6 +1326,7 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
                         int64_t uf, vf;
                         if (a.mode == 0) { uf = j; vf = l; }
                         else if (a.mode == 1) { uf = i * k + j; vf = i * k + l; }
+                        else if (a.mode == 3) { uf = row_rel * k + j; vf = row_rel * k + l; }     // ids into the flattened nodes of THIS call: what the encoder builds (models/ss_gnn.py:463-464)
                         else { uf = nrow[j]; vf = nrow[l]; }
                         a.edge_index[pos] = uf;
                         a.edge_index[a.ld + pos] = vf;
@@ -1364,6 +1365,7 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
                     int64_t uf, vf;
                     if (a.mode == 0) { uf = j; vf = l; }
                     else if (a.mode == 1) { uf = i * k + j; vf = i * k + l; }
+                    else if (a.mode == 3) { uf = row_rel * k + j; vf = row_rel * k + l; }
                     else { uf = nrow[j]; vf = nrow[l]; }
                     a.edge_index[pos] = uf;
                     a.edge_index[a.ld + pos] = vf;
@@ -1484,16 +1486,15 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill_staged(UgsFillArgs a) {
         const uint2 *items = a.stage + row_rel * UGS_STAGE_ITEMS;
         const int64_t *nrow = a.nodes + row_rel * k;
         int64_t i = 0;
-        if (a.mode == 1) {
-            const int64_t row = a.row_begin + row_rel;
-            i = (P.num_graphs == 1) ? row : row % a.m;
-        }
+        const int64_t row = a.row_begin + row_rel;
+        if (a.mode == 1) i = (P.num_graphs == 1) ? row : row % a.m;
         for (int t = lane; t < n && t < UGS_STAGE_ITEMS && e0 + t < a.ld; t += GS) {   // ld is also the buffers' capacity
             const uint2 x = items[t];
             const int j = (int)(x.y & 0xFFu), l = (int)(x.y >> 8);
             int64_t uf, vf;
             if (a.mode == 0) { uf = j; vf = l; }
             else if (a.mode == 1) { uf = i * k + j; vf = i * k + l; }
+            else if (a.mode == 3) { uf = row_rel * k + j; vf = row_rel * k + l; }
             else { uf = nrow[j]; vf = nrow[l]; }
             a.edge_index[e0 + t] = uf;
             a.edge_index[a.ld + e0 + t] = vf;

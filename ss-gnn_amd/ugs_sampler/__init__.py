@@ -24,6 +24,7 @@ __all__ = ["sample", "create_preproc", "destroy_preproc", "has_graphlets", "get_
 
 _EDGE_MODES = {"local": 0, "flat": 1, "global": 2}
 _BATCH_MODES = {"sample": 0, "graph": 1, "global": 2}
+_FILL_MODES = dict(_BATCH_MODES, batch=3)      # Plan.fill only: row * k + local index (the encoder's batch-level edge index)
 _I32_MIN, _I32_MAX = -(2 ** 31), 2 ** 31 - 1
 
 
@@ -351,7 +352,7 @@ class Plan:
         else:
             edge_index, edge_src = out
         stream = torch.cuda.current_stream().cuda_stream
-        check(lib.ugs_plan_fill(self._h, m, self.k, _BATCH_MODES[mode] if mode in _BATCH_MODES else _EDGE_MODES[mode],
+        check(lib.ugs_plan_fill(self._h, m, self.k, _FILL_MODES[mode] if mode in _FILL_MODES else _EDGE_MODES[mode],
                                 int(extra_node_offset), int(row_begin), int(row_count), stream, nodes.data_ptr(),
                                 edge_ptr.data_ptr(), edge_index.data_ptr(), edge_index.stride(0) if edge_index.size(1) else 0,
                                 edge_src.data_ptr()))
@@ -364,6 +365,17 @@ class Plan:
         if row_count is None:
             row_count = self.num_graphs * m - row_begin
         return GraphStep(self, m, mode, int(row_begin), int(row_count), edge_capacity)
+
+    def encoder_inputs(self, m_per_graph, seed=42, row_begin=0, row_count=None):
+        """What the reference's encoder derives from the sampler's output (src/gps/gps/models/ss_gnn.py:441-468), straight from
+        the kernels: (nodes clamped at 0 [rows*k], validity mask [rows*k], edge_index numbered row*k + local index [2,Es],
+        edge_src [Es], batch vector [rows*k]) as device tensors -- no repeat_interleave (and no host synchronisation for it)
+        on the consumer's side."""
+        nodes, edge_ptr, total = self.walk(m_per_graph, "sample", seed, row_begin, row_count)
+        edge_index, edge_src = self.fill(m_per_graph, nodes, edge_ptr, total, "batch", row_begin)
+        flat = nodes.flatten()
+        batch = torch.arange(nodes.size(0), device=nodes.device).repeat_interleave(self.k)
+        return flat.clamp(min=0), flat >= 0, edge_index, edge_src, batch
 
     def sample_rows(self, m_per_graph, mode="sample", seed=42, row_begin=0, row_count=None):
         """(nodes, edge_index, edge_ptr, edge_src) for rows [row_begin, row_begin+row_count) as device tensors."""

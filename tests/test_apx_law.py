@@ -1,0 +1,46 @@
+"""CPU: the enumerated output law of APX-UGS (oracle/apx_oracle.py) pinned against the sequential restatement csrc/ugs_apx.cpp,
+which is bit-exact with the reference (tests/test_apx_entry.py).  The restatement needs minutes of CPU per hundred samples (the
+reference's acceptance probability is ~3e-6 per trial), so its rows were drawn once in the build container and are committed as
+counts (tests/golden/apx_host_counts.json); this test recomputes the law and checks counts, support and failure rate against it.
+tests/test_gpu_apx.py then holds the GPU variant to the same law."""
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_sequential_restatement_follows_the_enumerated_law():
+    import apx_oracle as ao
+    fix = json.load(open(os.path.join(ROOT, "tests", "golden", "apx_host_counts.json")))
+    eps, k = fix["epsilon"], fix["k"]
+    for name, g in fix["graphs"].items():
+        edges = [tuple(e) for e in g["edges"]]
+        adj = ao.adjacency(max(max(e) for e in edges) + 1, edges)
+        pos, est = ao.order(adj, k, eps)
+        law, acc = ao.law_k3(adj, pos, est, eps)
+        assert abs(sum(law.values()) - 1.0) < 1e-9
+        counts = {tuple(key): v for key, v in g["counts"]}
+        got = sum(counts.values())
+        assert got >= 200
+        pval, chi2, dof = ao.chi_square_p(counts, law)
+        assert pval > 1e-3, f"{name}: chi2 {chi2:.1f} on {dof} dof, p = {pval:.2e}"
+        # samples without an accepted trial among 10^6 are dropped (reference :411, :450-453)
+        p_fail = (1.0 - acc) ** 1_000_000
+        assert abs((g["requested"] - got) - g["requested"] * p_fail) <= 5.0 * np.sqrt(g["requested"] * p_fail * (1 - p_fail)) + 3
+
+
+def test_a_fresh_call_of_the_restatement_lands_in_the_support():
+    """a handful of rows drawn now (seconds), as a guard that fixture and library still describe the same algorithm"""
+    import torch
+    import apx_oracle as ao
+    import apx_ugs_sampler
+    edges = [(0, 1), (1, 2), (2, 3), (3, 0), (0, 4), (1, 4)]
+    adj = ao.adjacency(5, edges)
+    pos, est = ao.order(adj, 3, 0.9)
+    law, _ = ao.law_k3(adj, pos, est, 0.9)
+    s, p = apx_ugs_sampler.sample_batch(torch.tensor(edges).t().contiguous(), torch.tensor([0, 6]), 4, 3, seed=11, epsilon=0.9)
+    assert s.shape[0] == 3 and p.tolist() == list(range(s.shape[1] + 1))
+    for row in s.t().tolist():
+        assert law.get(tuple(row), 0.0) > 1e-6

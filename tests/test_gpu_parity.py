@@ -514,3 +514,29 @@ def test_dynamic_split_with_rows_handed_on_to_the_next_tier():
     P.close()
     plan.close()
     ugs_sampler.clear_cache()
+
+
+def test_encoder_inputs_equal_what_the_consumer_derives():
+    """N1 epilogue: Plan.encoder_inputs (fill numbering row*k + local index, clamped nodes, mask, batch vector) against the torch
+    operations of the reference's encoder (src/gps/gps/models/ss_gnn.py:441-468) applied to the ordinary output -- including rows
+    of a degenerate graph (all -1) and a row sub-range."""
+    import torch
+    import ugs_sampler
+    import ugs_workloads as wl
+    ei, ptr = wl.tu_batch(18, 20, 6)
+    ptr = np.concatenate([ptr, [ptr[-1] + 2]])                                 # a last graph with 2 < k vertices: rows of -1
+    ei_t, ptr_t = torch.from_numpy(ei), torch.from_numpy(ptr)
+    m, k = 40, 4
+    plan = ugs_sampler.Plan.from_batch(ei_t, ptr_t, k)
+    for row_begin, row_count in ((0, None), (37, 150)):
+        nodes, eidx, eptr, esrc = plan.sample_rows(m, "sample", 9, row_begin, row_count)
+        B = nodes.size(0)
+        dev = nodes.device
+        stacked = nodes.flatten()
+        want_edge = torch.repeat_interleave(torch.arange(0, B, device=dev), eptr[1:] - eptr[:-1]) * k + eidx
+        got = plan.encoder_inputs(m, 9, row_begin, row_count)
+        assert torch.equal(got[0], stacked.clamp(min=0)) and torch.equal(got[1], stacked >= 0)
+        assert torch.equal(got[2], want_edge) and torch.equal(got[3], esrc)
+        assert torch.equal(got[4], torch.repeat_interleave(torch.arange(0, B, device=dev), k))
+    assert not bool(plan.encoder_inputs(m, 9)[1].all())                        # the degenerate graph's rows are masked out
+    plan.close()
