@@ -8,8 +8,8 @@
 // Here the SAME algorithm runs with one generator per (sample, trial): every lane runs whole trials, all samples and thousands
 // of trials at a time, and a sample's result is its accepted trial with the SMALLEST index -- a deterministic function of
 // (graph, seed), independent of how trials are spread over lanes.  Parity with the reference is statistical: the output law is
-// the same (oracle/apx_oracle.py enumerates it; tests/test_apx_law.py pins the enumeration against the sequential restatement,
-// tests/test_gpu_apx.py checks the GPU rows against it).  The APX-DD order (:52-168) is computed on the host (ugs_apx_common.h)
+// the same (the tests enumerate it exactly for k = 3: tests/test_apx_law.py pins the enumeration against the sequential
+// restatement, tests/test_gpu_apx.py checks the GPU rows against it).  The APX-DD order (:52-168) is computed on the host (ugs_apx_common.h)
 // with a counter-based generator.  Only the first graph is sampled and ptr[0]:ptr[1] is a range of edge COLUMNS, failed samples
 // are dropped, as in the reference.
 #include "../../include/ugs_mi355.h"
