@@ -153,6 +153,12 @@ template <int GS> struct Grp {
     }
     __device__ __forceinline__ bool any(bool p) const { return ballot(p) != 0ull; }
     __device__ __forceinline__ uint64_t lt_mask() const { return (1ull << lane) - 1ull; }
+    // number of set bits of a group ballot below this lane.  One walk per wave: v_mbcnt_lo/hi count the bits below the lane in
+    // two instructions (the shift-mask-popcount form takes five)
+    __device__ __forceinline__ uint32_t below(uint64_t m) const {
+        if (GS == 64) return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        return (uint32_t)__popcll(m & lt_mask());
+    }
     // value of lane `src` of the group.  One walk per wave: `src` is wave-uniform, so v_readlane puts the result in a scalar
     // register and everything derived from it (row bounds, loop limits, hash slot of the chosen vertex) stays scalar.
     __device__ __forceinline__ uint32_t bcast(uint32_t v, int src) const {
@@ -734,7 +740,7 @@ template <int GS>
 __device__ __forceinline__ void stage_hits(StageCtx &sc, const Grp<GS> &g, bool in_s, uint32_t w, uint32_t p, uint32_t size) {
     const uint64_t im = g.ballot(in_s);
     if (!im) return;
-    const uint32_t slot = sc.ne + (uint32_t)__popcll(im & g.lt_mask());
+    const uint32_t slot = sc.ne + g.below(im);
     if (in_s && slot < UGS_STAGE_ENTRIES) sc.EL[slot] = make_uint4(p, w, size - 1u, 0u);
     sc.ne += (uint32_t)__popcll(im);
 }
@@ -760,10 +766,12 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
             }
         }
         STAMP_SUB_END_OF(1, 6);
-        const bool inserted = cand && seen == kEmpty;
-        const bool found = cand && seen != kEmpty && (seen & kKeyMask) == w;
-        in_s = found && (seen & kInS) != 0u;
-        const bool fresh_dup = found && (seen & kFresh) != 0u;
+        // `seen` of a lane that is no candidate keeps kKeyMask: not empty, its key part (all ones) equals no vertex, so every
+        // predicate below is a single compare whose ballot the compiler takes straight from v_cmp
+        // (the key part of kEmpty is all ones too), and the flags are tested together with the key
+        const bool inserted = seen == kEmpty;
+        in_s = (seen & (kKeyMask | kInS)) == (w | kInS);                     // found, and a member of the sample
+        const bool fresh_dup = (seen & (kKeyMask | kFresh)) == (w | kFresh);  // found, and inserted by this very chunk
         SP::sync();
         // A vertex is NEW if this chunk inserted it; its place in D is that of its FIRST occurrence in the row.  Lanes
         // that met a key inserted by this very chunk (a repeated neighbour, e.g. both directions of a PyG edge) are
@@ -779,12 +787,15 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
             dupm &= ~grp;
         }
         if (inserted) ws.HK[slot] = w;                            // the chunk is over for this key: drop kFresh
-        ecount += 2u * (uint32_t)__popcll(g.ballot(in_s && w != v)) + (uint32_t)__popcll(g.ballot(in_s && w == v));
+        {   // entries to earlier members count twice (the mirror entry), entries to the scanned vertex itself once
+            const uint64_t im = g.ballot(in_s), sm = g.ballot(w == v);
+            ecount += 2u * (uint32_t)__popcll(im & ~sm) + (uint32_t)__popcll(im & sm);
+        }
         if constexpr (STG) { if (sc.on) stage_hits<GS>(sc, g, in_s, w, p, size); }
         const uint64_t fm = g.ballot(first);
         const uint32_t nnew = (uint32_t)__popcll(fm);
         if (c + nnew > ws.cap) return false;
-        if (first) ws.D[c + (uint32_t)__popcll(fm & g.lt_mask())] = w;
+        if (first) ws.D[c + g.below(fm)] = w;
         c += nnew;
         hcount += nnew;
         SP::sync();
@@ -797,8 +808,11 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
                 slot = (slot + 1) & ws.hmask;
             }
         }
-        in_s = cand && seen != kEmpty && (seen & kKeyMask) == w && (seen & kInS) != 0u;
-        ecount += 2u * (uint32_t)__popcll(g.ballot(in_s && w != v)) + (uint32_t)__popcll(g.ballot(in_s && w == v));
+        in_s = (seen & (kKeyMask | kInS)) == (w | kInS);                     // kEmpty (no candidate, or not seen) matches no vertex
+        {
+            const uint64_t im = g.ballot(in_s), sm = g.ballot(w == v);
+            ecount += 2u * (uint32_t)__popcll(im & ~sm) + (uint32_t)__popcll(im & sm);
+        }
         if constexpr (STG) { if (sc.on) stage_hits<GS>(sc, g, in_s, w, p, size); }
     }
     return true;
@@ -1320,7 +1334,7 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
 #pragma unroll
                     for (int t = 7; t >= 0; --t) l = (sv[t] == wv[u]) ? t : l;
                     const uint64_t mk = g.ballot(l >= 0);
-                    const int64_t pos = w_off + __popcll(mk & g.lt_mask());
+                    const int64_t pos = w_off + g.below(mk);
                     if (l >= 0 && pos < a.ld) {                           // ld is also the capacity of the caller's edge buffers
                         const int j = jj[u];
                         int64_t uf, vf;
@@ -1359,7 +1373,7 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
                 int l = -1;
                 if (wv[u] != kEmpty) { for (int t = 0; t < k; ++t) if (SV[t] == wv[u]) { l = t; break; } }
                 const uint64_t mk = g.ballot(l >= 0);
-                const int64_t pos = w_off + __popcll(mk & g.lt_mask());
+                const int64_t pos = w_off + g.below(mk);
                 if (l >= 0 && pos < a.ld) {
                     const int j = jj[u];
                     int64_t uf, vf;
