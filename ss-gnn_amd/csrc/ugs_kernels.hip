@@ -480,7 +480,7 @@ __device__ __forceinline__ Pick stage_final_reg(const Work<LdsSpace> &ws, const 
     if (valid && t < n_old) pos = OLD[t];
     if (valid) key = ws.D[pos];
     const uint32_t rank = rank_in_registers(g, valid, mod_magic(key, B, M, S), S + 1u);
-    const uint64_t hm = __ballot(valid && rank == rsel);
+    const uint64_t hm = __ballot(rank == rsel) & __ballot(valid);
     const int src = hm ? (__ffsll((long long)hm) - 1) : 0;
     return Pick{g.bcast(key, src), g.bcast(pos, src)};
 }
@@ -745,12 +745,14 @@ __device__ __forceinline__ void stage_hits(StageCtx &sc, const Grp<GS> &g, bool 
     sc.ne += (uint32_t)__popcll(im);
 }
 
-// One chunk of an adjacency row: lane holds entry e (neighbour, rank) at CSR position p if `valid` (a plan has < 2^31 entries).
+// One chunk of an adjacency row: lane holds entry e (neighbour, rank) at CSR position p (a plan has < 2^31 entries); lanes
+// without an entry hold kNoEntry, whose rank -1 fails the suffix filter, so `cand` is one signed compare (ranks are < 2^30).
+#define UGS_NO_ENTRY make_int2(0, -1)
 template <int GS, class SP, bool ADD, bool STG>
 __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g, uint32_t v, uint32_t root_vi, uint32_t size, uint32_t &c,
-                                           uint32_t &hcount, uint32_t &ecount, StageCtx &sc, bool valid, int2 e, uint32_t p) {
-    const uint32_t w = valid ? (uint32_t)e.x : 0u;
-    const bool cand = valid && (uint32_t)e.y >= root_vi;
+                                           uint32_t &hcount, uint32_t &ecount, StageCtx &sc, int2 e, uint32_t p) {
+    const uint32_t w = (uint32_t)e.x;
+    const bool cand = e.y >= (int)root_vi;
     uint32_t slot = hash_slot(w, ws.hmask);
     bool in_s = false;
     if (ADD) {
@@ -825,10 +827,9 @@ __device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, c
                                          uint32_t &ecount, uint32_t r0, uint32_t r1, StageCtx &sc) {
     for (uint32_t base = r0; base < r1; base += GS) {
         const uint32_t p = base + (uint32_t)g.lane;
-        const bool valid = p < r1;
-        int2 e = make_int2(0, 0);
-        if (valid) e = P.adj[p];
-        if (!scan_chunk<GS, SP, ADD, STG>(ws, g, v, root_vi, size, c, hcount, ecount, sc, valid, e, p)) return false;
+        int2 e = UGS_NO_ENTRY;
+        if (p < r1) e = P.adj[p];
+        if (!scan_chunk<GS, SP, ADD, STG>(ws, g, v, root_vi, size, c, hcount, ecount, sc, e, p)) return false;
     }
     return true;
 }
@@ -852,14 +853,14 @@ __device__ __forceinline__ bool scan_prow(const Work<SP> &ws, const Grp<64> &g, 
     if (n0 >= (uint32_t)P.prow_first) {                                          // the row reaches into the lines not fetched yet
         if (g.lane >= P.prow_first && g.lane <= (int)n0) e0 = P.prow[(vrow << P.prow_shift) + g.lane];
     }
-    if (n0 && !scan_chunk<64, SP, ADD, STG>(ws, g, v, root_vi, size, c, hcount, ecount, sc, (uint32_t)(g.lane - 1) < n0, e0, start + (uint32_t)g.lane - 1u)) return false;
+    if ((uint32_t)(g.lane - 1) >= n0) e0 = UGS_NO_ENTRY;                        // the header's lane and the lanes behind the row
+    if (n0 && !scan_chunk<64, SP, ADD, STG>(ws, g, v, root_vi, size, c, hcount, ecount, sc, e0, start + (uint32_t)g.lane - 1u)) return false;
     const uint32_t r1 = start + deg;
     for (uint32_t base = start + inl; base < r1; base += 64) {
         const uint32_t p = base + (uint32_t)g.lane;
-        const bool valid = p < r1;
-        int2 e = make_int2(0, 0);
-        if (valid) e = P.adj[p];
-        if (!scan_chunk<64, SP, ADD, STG>(ws, g, v, root_vi, size, c, hcount, ecount, sc, valid, e, p)) return false;
+        int2 e = UGS_NO_ENTRY;
+        if (p < r1) e = P.adj[p];
+        if (!scan_chunk<64, SP, ADD, STG>(ws, g, v, root_vi, size, c, hcount, ecount, sc, e, p)) return false;
     }
     return true;
 }

@@ -44,8 +44,8 @@ template <bool ADD> __global__ __launch_bounds__(64, 5) void probe_chunk(uint32_
     PROBE_PRE
     StageCtx sc; sc.EL = pw.EL; sc.ne = rsel & 3; sc.on = stage != nullptr;
     uint32_t hcount = c + 3, ecount = rsel >> 8, cc = c;
-    const int2 e = adj[threadIdx.x];
-    const bool ok = scan_chunk<64, LdsSpace, ADD, true>(pw.ws, g, rsel, c >> 3, 3, cc, hcount, ecount, sc, threadIdx.x < 40, e, (int64_t)threadIdx.x + 1000);
+    int2 e = UGS_NO_ENTRY; if (threadIdx.x < 40) e = adj[threadIdx.x];
+    const bool ok = scan_chunk<64, LdsSpace, ADD, true>(pw.ws, g, rsel, c >> 3, 3, cc, hcount, ecount, sc, e, threadIdx.x + 1000u);
     out[threadIdx.x] = lds[(threadIdx.x + c) & 63] + cc + hcount + ecount + sc.ne + (ok ? 1u : 0u);
 }
 __global__ __launch_bounds__(64, 5) void probe_draw(uint32_t *out, const uint32_t *in, uint32_t c, uint32_t rsel) {
