@@ -89,6 +89,27 @@ def test_every_walk_tier_gives_the_same_rows(tier, product, orc, monkeypatch):
     _same(calls, product, orc, f"tier {tier}")
 
 
+@pytest.mark.parametrize("env", [{"UGS_NO_PROW": "1"}, {"UGS_PROW_SHIFT": "3"}, {"UGS_PROW_SHIFT": "6", "UGS_PROW_FIRST": "16"},
+                                 {"UGS_PROW_SHIFT": "5", "UGS_PROW_FIRST": "32"}])
+@pytest.mark.parametrize("tier", ["1", "2"])
+def test_row_layouts_of_the_wave_tiers_give_the_same_rows(env, tier, product, orc, monkeypatch):
+    """The one-walk-per-wave tiers read a vertex's row from its padded block (header + first entries, the rest of the block and
+    of the row on demand) or, without padded rows, through the row pointer: block sizes from 8 to 64 entries, a first fetch
+    shorter than the block, and the row-pointer variant must all produce the reference's rows (degrees from 0 to several
+    hundred, so that every path -- row inside the first fetch, inside the block, continued in the CSR -- is taken)."""
+    monkeypatch.setenv("UGS_FORCE_TIER", tier)
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    rng = random.Random(23)
+    calls = []
+    for n, p, k, m in [(40, 0.15, 5, 64), (90, 0.35, 6, 80), (260, 0.3, 5, 48), (500, 0.5, 4, 24)]:
+        e = [(u, v) for u in range(n) for v in range(u + 1, n) if rng.random() < p]
+        e += [(0, 0), (3, 3)] + [(v, u) for u, v in e[: len(e) // 3]]            # self loops, some reversed duplicates
+        ei = np.array(e, dtype=np.int64).T.reshape(2, -1)
+        calls.append(dict(fn="sample_batch", edge_index=ei, ptr=np.array([0, n + 2], dtype=np.int64), m=m, k=k, mode="sample", seed=5))
+    _same(calls, product, orc, f"row layout {env} tier {tier}")
+
+
 def test_hub_graph_uses_global_memory_tier(product, orc):
     """a hub with 6000 neighbours: candidate sets of thousands of vertices (bucket chain past 2357 / 5087) exceed every
     LDS tier and run in the global-memory workspace tier."""
