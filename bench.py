@@ -525,8 +525,8 @@ def bench_drop_in(name, ugs_sampler, ei_t, ptr_t, m, k, mode, dev, reps):
     del o
     return {"workload": name, "rows": rows, "host_visible_ms": round(dt_host * 1e3, 3), "host_visible_subgraphs_per_s": round(rows / dt_host, 1),
             "device_out_ms": round(dt_dev * 1e3, 3), "device_out_subgraphs_per_s": round(rows / dt_dev, 1), "reps": reps,
-            "note": "host tensors in every call (the reference's interface): per call the library assigns columns to graphs, renumbers, hashes (LRU key), "
-                    "looks the plan up, samples, and copies out"}
+            "note": "host tensors in every call (the reference's interface): per call the library hashes the batch's bytes (a batch seen before is matched as "
+                    "a whole; the per-graph LRU is touched as the general path would), samples, and copies out"}
 
 
 def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
