@@ -51,6 +51,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-reference", action="store_true", help="skip timing the reference C++ itself (oracle/_ref) on the headline workload; its preprocessing takes about half a minute on C5")
     ap.add_argument("--walk-share", type=int, default=80, help="percent of each CU the walk kernels occupy while a collation runs beside them (N > 1)")
     ap.add_argument("--force-collate", action="store_true", help="run the multi-GPU collation path even with one rank (rehearsal)")
+    ap.add_argument("--rehearse", action="store_true", help="N ranks on ONE GPU over gloo (every rank uses cuda:0): exercises the multi-rank control flow "
+                    "of this script where only one GPU is at hand; the numbers mean nothing")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -309,12 +311,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.force_collate:
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", os.environ.get("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- workload + plan (host preprocessing and upload are NOT timed: warm-cache state) --------------------------
     t0 = time.time()
@@ -353,6 +360,29 @@ def main():
         extras["weak_scaling"] = {"value": round(wjob.total_rows * wsteps / wel, 1), "ms_per_step": round(wel / wsteps * 1e3, 4), "steps": wsteps,
                                   "global_rows": wjob.total_rows, "rows_per_gpu": wjob.row_count, "collate_ms_per_step": round(wcms, 4) if wcms else None}
         del wjob
+
+    # the collated batch of one more step against rank 0's own rows (placement check of the exchange step): a collective, so
+    # every rank takes part before the ranks part ways
+    if use_collate:
+        job.totals = None
+        last = job.run_steps(1000, 1)
+        torch.cuda.synchronize()
+        if rank == 0:
+            b = 1000 % job.nsets
+            c_nodes, c_eidx, c_eptr, c_esrc = last
+            rb, rc_ = job.row_begin, job.row_count
+            assert int(c_eptr[-1]) >= int(job.eptr[b][-1]) and bool((c_eptr[1:] >= c_eptr[:-1]).all()), "collated edge_ptr is not a scan"
+            assert torch.equal(c_nodes[rb:rb + rc_], job.nodes[b]), "collated nodes differ"
+            assert torch.equal(c_eptr[rb:rb + rc_ + 1] - c_eptr[rb], job.eptr[b]), "collated edge_ptr differs"
+            e0, e1 = int(c_eptr[rb]), int(c_eptr[rb + rc_])
+            assert torch.equal(c_eidx[:, e0:e1], job.eidx[b][:, : e1 - e0]) and torch.equal(c_esrc[e0:e1], job.esrc[b][: e1 - e0]), "collated edges differ"
+            if world > 1:      # and the rows of the OTHER ranks: the same rows sampled here, unsharded (row i depends only on (seed, i))
+                chk_n = min(20_000, job.total_rows - rc_)
+                o_nodes, o_eidx, o_eptr, o_esrc = plan.sample_rows(m_total, args.mode, 42 + 1000, rb + rc_, chk_n)
+                assert torch.equal(c_nodes[rb + rc_:rb + rc_ + chk_n], o_nodes), "collated rows of another rank differ from the unsharded rows"
+                f0 = int(c_eptr[rb + rc_])
+                assert torch.equal(c_eptr[rb + rc_:rb + rc_ + chk_n + 1] - f0, o_eptr) and torch.equal(c_eidx[:, f0:f0 + o_eidx.size(1)], o_eidx) \
+                    and torch.equal(c_esrc[f0:f0 + o_esrc.numel()], o_esrc), "collated edges of another rank differ from the unsharded rows"
 
     if rank != 0:
         dist.barrier()
@@ -446,18 +476,6 @@ def main():
                 cpu_all = cpu_all_cores(args.workload, args.mode, m_total, G, per)
             except Exception as e:   # noqa: BLE001
                 cpu_all = {"error": str(e)[:200]}
-
-    # the collated batch of the last timed step against this rank's own rows (placement check of the exchange step)
-    if use_collate:
-        job.totals = None
-        last = job.run_steps(1000, 1)
-        torch.cuda.synchronize()
-        b = 1000 % job.nsets
-        c_nodes, c_eidx, c_eptr, c_esrc = last
-        assert torch.equal(c_nodes[row_begin:row_begin + row_count], job.nodes[b]), "collated nodes differ"
-        assert torch.equal(c_eptr[row_begin:row_begin + row_count + 1] - c_eptr[row_begin], job.eptr[b]), "collated edge_ptr differs"
-        e0, e1 = int(c_eptr[row_begin]), int(c_eptr[row_begin + row_count])
-        assert torch.equal(c_eidx[:, e0:e1], job.eidx[b][:, : e1 - e0]) and torch.equal(c_esrc[e0:e1], job.esrc[b][: e1 - e0]), "collated edges differ"
 
     out = {"metric": "k_subgraphs_sampled_per_sec", "value": round(value, 1), "unit": "k-subgraphs/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,

@@ -122,11 +122,27 @@ class Collator:
         return self.msg
 
     def exchange(self):
+        if self.dev.type == "cuda" and dist.get_backend(self.group) == "gloo":
+            return self._exchange_through_host()
         if self.all_ranks:
             dist.all_gather_into_tensor(self.inbox, self.msg.reshape(1, -1), group=self.group)
         else:
             blocks = [self.inbox[r] for r in range(self.world)] if self.is_dst else None
             dist.gather(self.msg, blocks, dst=self.dst, group=self.group)
+
+    def _exchange_through_host(self):
+        """device messages over a CPU-only backend (gloo): staged through host memory -- a rehearsal path (several ranks on
+        one GPU), not the production path, which hands the device buffers to RCCL"""
+        msg = self.msg.cpu()
+        if self.all_ranks:
+            inbox = torch.empty((self.world, self.nbytes), dtype=torch.uint8)
+            dist.all_gather_into_tensor(inbox, msg.reshape(1, -1), group=self.group)
+            self.inbox.copy_(inbox)
+        else:
+            blocks = [torch.empty(self.nbytes, dtype=torch.uint8) for _ in range(self.world)] if self.is_dst else None
+            dist.gather(msg, blocks, dst=self.dst, group=self.group)
+            if self.is_dst:
+                self.inbox.copy_(torch.stack(blocks))
 
     # -- `world` messages -> the batch ---------------------------------------------------------------------------------------
     def unpack(self):

@@ -167,3 +167,23 @@ def test_collation_kernels_equal_the_torch_path_and_the_oracle(mode, world):
         assert int(got[2][-1]) == tot == int(ref[2][-1])
         for g, r_, w in ((got[0], ref[0], nodes), (got[2], ref[2], eptr), (got[1][:, :tot], ref[1][:, :tot], eidx), (got[3][:tot], ref[3][:tot], esrc)):
             assert np.array_equal(g, w) and np.array_equal(r_, w)
+
+
+@pytest.mark.timeout(300)
+def test_bench_multi_rank_control_flow_on_one_gpu():
+    """`bench.py --gpus 2 --rehearse`: two ranks started by the script itself, both on this GPU, messages staged through the host
+    over gloo -- every step of the N > 1 path (row shards, capacity agreement, double-buffered sampling, collation each step,
+    placement check of both ranks' rows against the unsharded rows, the weak-scaling extra, orderly shutdown) runs; the numbers
+    mean nothing.  The driver's scaling run is the same script over RCCL with one GPU per rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse", "--workload", "er_200000_4000000_100000_8",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["global_rows"] == 100_000 and line["config"]["rows_per_gpu"] == 50_000
+    assert line["collate_ms_per_step"] is not None and line["extras"]["weak_scaling"]["global_rows"] == 200_000
