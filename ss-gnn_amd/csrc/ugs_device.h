@@ -72,7 +72,7 @@ struct UgsWalkArgs {
     int64_t row_begin;       // first of the G*m rows produced by this call
     int64_t row_count;
     int64_t *nodes;          // [row_count, k]
-    uint32_t *counts;        // [row_count] edge entries per row
+    uint32_t *counts;        // [row_count] edge entries per row; top bit (UGS_COUNT_STAGED) = the row's items are in `stage`
     // overflow hand-off between tiers: rows whose candidate set outgrew the tier's LDS capacity
     const int64_t *in_list;  // NULL: process rows 0..row_count-1; else process in_list[0..*in_count)
     const uint32_t *in_count;
@@ -95,10 +95,10 @@ struct UgsWalkArgs {
     // get invalidated), so a static split ends with the unluckiest wave.
     unsigned long long *work_next;
     uint2 *stage;            // [row_count, UGS_STAGE_ITEMS]: x = batch column, y = source local index | target local index << 8
-    uint8_t *staged;         // [row_count] 1 = row's items are in `stage`
     int64_t *ulist;          // rows (relative) with edges that are NOT staged
     uint32_t *ucount;
 };
+#define UGS_COUNT_STAGED 0x80000000u
 #define UGS_STAGE_ENTRIES 32    /* undirected hits a walk can hold in LDS */
 #define UGS_STAGE_ITEMS 64      /* directed items per row in the staging buffer */
 
@@ -113,7 +113,7 @@ struct UgsFillArgs {
     int64_t ld;
     int64_t *edge_src;
     const uint2 *stage;        // staging left by the walk of the same rows (NULL: every row is filled from its adjacency rows)
-    const uint8_t *staged;
+    const uint32_t *counts;    // the walk's per-row counts: their top bit says whether the row was staged
     const int64_t *ulist;      // with staging: the rows the row-reading kernel still has to do
     const uint32_t *ucount;
 };

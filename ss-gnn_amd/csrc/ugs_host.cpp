@@ -438,7 +438,7 @@ struct ugs_plan {
     PoolBuf counts, ovf1, ovf2, ovfcnt, scantmp, gws;
     // edges staged by the last walk (UgsWalkArgs::stage) and the call they belong to: a fill of exactly those rows into/from
     // the same nodes buffer expands them; any other fill reads the adjacency rows again
-    PoolBuf stage, staged, ulist, work;   // work: 3 x u64 next-item counters (one per walk launch of a call)
+    PoolBuf stage, ulist, work;   // work: 3 x u64 next-item counters (one per walk launch of a call)
     // stream order between calls: a plan's scratch is reused by every call, so a call on another stream than the previous one
     // first waits (on the device) for that call's last kernel
     hipEvent_t last_ev = nullptr;
@@ -641,7 +641,7 @@ void destroy_plan(ugs_plan *p) {
     if (p->last_ev) (void)hipEventDestroy(p->last_ev);
     if (p->blob_buf.p) pool_put(p->blob_buf); else if (p->blob) (void)hipFree(p->blob);
     pool_put(p->counts); pool_put(p->ovf1); pool_put(p->ovf2); pool_put(p->ovfcnt); pool_put(p->scantmp);
-    pool_put(p->stage); pool_put(p->staged); pool_put(p->ulist); pool_put(p->work);
+    pool_put(p->stage); pool_put(p->ulist); pool_put(p->work);
     if (p->prow.p) { if (p->prow_pooled) pool_put(p->prow); else (void)hipFree(p->prow.p); p->prow = PoolBuf(); }
     if (p->gws.p) { (void)hipFree(p->gws.p); p->gws = PoolBuf(); }
     delete p;
@@ -1160,7 +1160,6 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
     plan->stg_valid = false;
     if (stg) {
         if (int rc = ensure(plan->stage, (size_t)row_count * UGS_STAGE_ITEMS * sizeof(uint2), plan->device, plan)) return rc;
-        if (int rc = ensure(plan->staged, (size_t)row_count, plan->device, plan)) return rc;
         if (int rc = ensure(plan->ulist, (size_t)row_count * sizeof(int64_t), plan->device, plan)) return rc;
     }
     if (may_overflow || stg) HIP_TRY(hipMemsetAsync(plan->ovfcnt.p, 0, 4 * sizeof(uint32_t), s));   // nothing else reads the counters
@@ -1186,7 +1185,7 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
     a.ovf_list = static_cast<int64_t *>(plan->ovf1.p);
     a.ovf_count = cnt + 0;
     if (stg) {
-        a.stage = static_cast<uint2 *>(plan->stage.p); a.staged = static_cast<uint8_t *>(plan->staged.p);
+        a.stage = static_cast<uint2 *>(plan->stage.p);
         a.ulist = static_cast<int64_t *>(plan->ulist.p); a.ucount = cnt + 3;
         plan->stg_valid = true; plan->stg_nodes = d_nodes; plan->stg_row_begin = row_begin; plan->stg_row_count = row_count;
         plan->stg_m = m_per_graph; plan->stg_k = k;
@@ -1268,7 +1267,7 @@ int ugs_plan_fill(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
     std::lock_guard<std::mutex> lk(plan->mu);
     if (plan->stg_valid && plan->stg_nodes == d_nodes && plan->stg_row_begin == row_begin && plan->stg_row_count == row_count &&
         plan->stg_m == m_per_graph && plan->stg_k == k) {
-        a.stage = static_cast<const uint2 *>(plan->stage.p); a.staged = static_cast<const uint8_t *>(plan->staged.p);
+        a.stage = static_cast<const uint2 *>(plan->stage.p); a.counts = static_cast<const uint32_t *>(plan->counts.p);
         a.ulist = static_cast<const int64_t *>(plan->ulist.p); a.ucount = static_cast<const uint32_t *>(plan->ovfcnt.p) + 3;
     }
     if (int rc = plan_enter(plan, static_cast<hipStream_t>(stream))) return rc;

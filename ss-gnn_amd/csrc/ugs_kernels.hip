@@ -912,7 +912,7 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
     int64_t *out = a.nodes + row_rel * k;
     if (gd.level < 0) {   // degenerate graph: m rows of -1, no edges (reference src/ugs_sampler_batch_extension.cpp:132-143)
         for (int j = g.lane; j < k; j += GS) out[j] = -1;
-        if (g.lane == 0) { a.counts[row_rel] = 0; if (a.staged) a.staged[row_rel] = 0; }
+        if (g.lane == 0) a.counts[row_rel] = 0;
         return true;
     }
     STAMP_DECL;
@@ -1037,13 +1037,11 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
     // nodes row: growth order, -1 padded (reference src/sampler.cpp:205-216, src/ugs_sampler_batch_extension.cpp:188-196)
     const int64_t off = gd.node_lo + a.extra_node_off;
     for (int j = g.lane; j < k; j += GS) out[j] = (j < (int)size) ? (int64_t)SV[j] + off : (int64_t)-1;
-    if (g.lane == 0) a.counts[row_rel] = nedges;
-    if (a.staged) {                                                              // staging is on for this call
+    // one word per row: the edge-entry count and, in its top bit, whether the row's items are staged (one store instead of two)
+    if (g.lane == 0) a.counts[row_rel] = nedges | (flush ? UGS_COUNT_STAGED : 0u);
+    if (a.stage) {                                                               // staging is on for this call
         if constexpr (STG) { if (flush) stage_flush(sc.ne, g, SV, (uint32_t)k, en, ecol, a.stage + row_rel * UGS_STAGE_ITEMS); }
-        if (g.lane == 0) {
-            a.staged[row_rel] = flush ? 1 : 0;
-            if (!flush && nedges != 0u) a.ulist[atomicAdd(a.ucount, 1u)] = row_rel;
-        }
+        if (g.lane == 0 && !flush && nedges != 0u) a.ulist[atomicAdd(a.ucount, 1u)] = row_rel;
     }
     STAMP_END(5);
     return true;
@@ -1204,7 +1202,7 @@ __global__ __launch_bounds__(kScanBlock) void ugs_scan_partials(const uint32_t *
     const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanPer;
     int64_t s = 0;
 #pragma unroll
-    for (int j = 0; j < kScanPer; ++j) if (base + j < rows) s += counts[base + j];
+    for (int j = 0; j < kScanPer; ++j) if (base + j < rows) s += counts[base + j] & ~UGS_COUNT_STAGED;
     int64_t tot;
     block_excl_scan(s, &tot, sh);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
@@ -1229,7 +1227,7 @@ __global__ __launch_bounds__(kScanBlock) void ugs_scan_final(const uint32_t *cou
     uint32_t v[kScanPer];
     int64_t s = 0;
 #pragma unroll
-    for (int j = 0; j < kScanPer; ++j) { v[j] = (base + j < rows) ? counts[base + j] : 0u; s += v[j]; }
+    for (int j = 0; j < kScanPer; ++j) { v[j] = (base + j < rows) ? (counts[base + j] & ~UGS_COUNT_STAGED) : 0u; s += v[j]; }
     int64_t tot;
     int64_t ex = block_excl_scan(s, &tot, sh) + (block_offs ? block_offs[blockIdx.x] : 0);
 #pragma unroll
@@ -1246,7 +1244,7 @@ __global__ __launch_bounds__(kScanBlock) void ugs_scan_small(const uint32_t *cou
         uint32_t v[kScanPer];
         int64_t s = 0;
 #pragma unroll
-        for (int j = 0; j < kScanPer; ++j) { v[j] = (base + j < rows) ? counts[base + j] : 0u; s += v[j]; }
+        for (int j = 0; j < kScanPer; ++j) { v[j] = (base + j < rows) ? (counts[base + j] & ~UGS_COUNT_STAGED) : 0u; s += v[j]; }
         int64_t tot;
         int64_t ex = carry + block_excl_scan(s, &tot, sh);
 #pragma unroll
@@ -1495,7 +1493,7 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill_staged(UgsFillArgs a) {
     const int k = a.k;
     const int64_t ngroups = (int64_t)gridDim.x * GROUPS;
     for (int64_t row_rel = (int64_t)blockIdx.x * GROUPS + gib; row_rel < a.row_count; row_rel += ngroups) {
-        if (!a.staged[row_rel]) continue;
+        if (!(a.counts[row_rel] & UGS_COUNT_STAGED)) continue;
         const int64_t e0 = a.edge_ptr[row_rel];
         const int n = (int)(a.edge_ptr[row_rel + 1] - e0);
         const uint2 *items = a.stage + row_rel * UGS_STAGE_ITEMS;
