@@ -21,15 +21,21 @@
 //     13 -> 29 -> 59 -> ... with every element in registers: atomicMin + atomicAdd on one LDS word per bucket give its
 //     first arrival and size, one DPP wave scan of the sizes over the bucket leaders gives every bucket's start, an
 //     atomicAdd-with-return hands out arrival slots into tiny per-bucket position lists from which every element counts
-//     the members above it; rank = start + count (stage_mat).  Every stage keeps its own order array, valid across
-//     growth steps while the removed candidate lies behind the prefix it covers.  The last stage materialises nothing:
+//     the members above it; rank = start + count (stage_mat).  Every stage keeps its own order array -- 16-bit POSITIONS in
+//     D, so the final stage names the chosen candidate's position and D is never searched -- valid across growth steps while
+//     the removed candidate lies behind the prefix it covers.  The last stage materialises nothing:
 //     the bucket holding position rng % |cut| is found by the scan and the element inside it by ballots (stage_final).
-//     Stages of up to 128 elements (one walk per wave) never touch the bucket table: a radix pass of ballots gives every
-//     lane the mask of its bucket-mates and popcounts do the rest (rank_in_registers / rank2_in_registers).  In the LDS
-//     tiers the stage index is a template parameter, so the chain constants are immediates (mat_at / final_at).
+//     Materialising stages of up to 128 elements and final stages of up to 64 (one walk per wave) never touch the bucket
+//     table: a radix pass of ballots gives every lane the mask of its bucket-mates and popcounts do the rest
+//     (rank_in_registers / rank2_in_registers).  In the LDS tiers the stage index is a template parameter, so the chain
+//     constants are immediates (mat_at / final_at).
 //     (The global-memory fallback tier keeps the simpler "peel round" formulation, select_in_order.)
 //   * the neighbour's order rank is stored next to the neighbour id in HBM (int2 adjacency), so the suffix filter is
-//     free; root records pack the alias row and both candidate root vertices in 24 bytes.
+//     free; root records pack the alias row and both candidate root vertices in 24 bytes; the one-walk-per-wave tiers read
+//     a vertex's row from a 128-byte-aligned padded block at an address computed from the vertex (header + first entries:
+//     one dependent memory round trip per growth step, scan_prow) -- ugs_device.h.
+//   * membership (seen / in sample) is one open-addressing table per walk in LDS, double hashing, inserted with atomicCAS by
+//     all lanes of a chunk at once (scan_chunk).
 //   * ballot + popcount prefix sums compact new candidates into D and (row-reading fill kernel) edges into the output.
 //   * the 64-lane tiers stage the induced edges they meet while scanning rows (stage_hits / stage_flush): the fill kernel
 //     of those rows is a plain expand (ugs_fill_staged); rows that do not fit are listed for the row-reading ugs_fill.
@@ -649,6 +655,8 @@ __device__ __forceinline__ void mat_at(const Work<LdsSpace> &ws, const Grp<GS> &
     constexpr int per = (int)((C::B + GS - 1) / GS);                          // these stages are full: L == B
     STAMP_SUB_BEGIN();
     if constexpr (GS == 64 && per <= 1) stage_mat_reg(ws, g, OLD, NEW, C::NOLD, C::B, C::M, C::S);
+    // (for 65..128 elements the register ranking, 203 VALU instructions, still beats the bucket-table variant with 2 elements per
+    // lane, 169 instructions but nine LDS round trips: 6.81 against 6.95 ms per 1M walks)
     else if constexpr (GS == 64 && per <= 2) stage_mat_reg2(ws, g, OLD, NEW, C::NOLD, C::B, C::M, C::S);
     else stage_mat<GS, nj_of(per)>(ws, g, OLD, NEW, C::NOLD, C::B, C::M, C::S);
     STAMP_SUB_END(per <= 1 ? 10 : (per <= 2 ? 11 : 12));
