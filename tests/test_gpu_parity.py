@@ -561,3 +561,45 @@ def test_encoder_inputs_equal_what_the_consumer_derives():
         assert torch.equal(got[4], torch.repeat_interleave(torch.arange(0, B, device=dev), k))
     assert not bool(plan.encoder_inputs(m, 9)[1].all())                        # the degenerate graph's rows are masked out
     plan.close()
+
+
+def test_presample_cache_assembles_batches_like_the_reference_trainer():
+    """ugs_sampler.presample.PresampleCache.load against a line-by-line numpy restatement of the reference's host loop
+    (gps/experiment.py:936-993) over the same cached per-graph results: nodes + ptr[g] (placeholder rows included), local edge
+    ids, edge_ptr / sample_ptr accumulation, edge_src + the number of batch columns owned by earlier graphs; a graph that was
+    never presampled takes the reference's placeholder path."""
+    import torch
+    import ugs_sampler
+    import ugs_workloads as wl
+    from ugs_sampler.presample import PresampleCache
+    m, k = 12, 4
+    graphs = [wl.tu_graph(n, e, 100 + i) for i, (n, e) in enumerate([(18, 20), (11, 14), (25, 40), (3, 2), (18, 19), (30, 45)])]
+    sizes = [18, 11, 25, 3, 18, 30]
+    cache = PresampleCache(m, k, "cuda:0")
+    host = {}
+    for i, (ei, n) in enumerate(zip(graphs, sizes)):
+        if i == 4:
+            continue                                                        # never presampled: placeholder path
+        t = torch.from_numpy(ei)
+        cache.add(i, t, n, seed=42 + i)
+        host[i] = [x.numpy() for x in ugs_sampler.sample_batch(t, torch.tensor([0, n]), m, k, mode="sample", seed=42 + i)]
+    for order in ([0, 1, 2, 3, 4, 5], [5, 2, 2, 4, 0], [3]):
+        ptr = np.cumsum([0] + [sizes[i] for i in order])
+        cols = np.concatenate([graphs[i] + ptr[j] for j, i in enumerate(order)], axis=1)
+        got = [t.cpu().numpy() for t in cache.load(torch.tensor(order), torch.from_numpy(ptr), torch.from_numpy(cols))]
+        # the reference's loop
+        off = [0]
+        for g in range(len(order) - 1):
+            off.append(off[-1] + int(((cols[0] >= ptr[g]) & (cols[0] < ptr[g + 1])).sum()))
+        nodes, edges, esrc, eptr, sptr, ce, cs = [], [], [], [0], [0], 0, 0
+        for g, i in enumerate(order):
+            if i in host:
+                n_g, e_g, p_g, _, s_g = host[i]
+            else:
+                n_g, e_g, p_g, s_g = np.full((m, k), -1, np.int64), np.zeros((2, 0), np.int64), np.zeros(m + 1, np.int64), np.zeros(0, np.int64)
+            nodes.append(n_g + ptr[g]); edges.append(e_g); esrc.append(s_g + off[g])
+            eptr += [ce + int(p_g[r + 1]) for r in range(n_g.shape[0])]
+            ce += e_g.shape[1]; cs += n_g.shape[0]; sptr.append(cs)
+        want = [np.concatenate(nodes), np.concatenate(edges, axis=1), np.array(eptr), np.array(sptr), np.concatenate(esrc)]
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b), order
