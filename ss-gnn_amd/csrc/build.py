@@ -16,15 +16,19 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 def build(force=False, verbose=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
-    objs = []
-    for src in SRCS:
+    from concurrent.futures import ThreadPoolExecutor
+
+    def compile_one(src):
         obj = os.path.splitext(src)[0] + ".o"
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
                "-x", "hip", "-c", src, "-o", obj]
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        objs.append(obj)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as pool:          # the walk kernels take a minute: the other sources compile beside them
+        objs = list(pool.map(compile_one, SRCS))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:
         print(" ".join(cmd))
