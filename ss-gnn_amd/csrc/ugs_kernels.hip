@@ -1114,23 +1114,29 @@ __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP <= 64 ||
     // single hot address answers in several microseconds); a walk's cost varies, so a static split ends with the unluckiest wave.
     // Two loops, two inlined copies of the walk: one shared loop measured 0.8 % slower on C5 (register allocation).
     if (a.work_next) {
-        // chunks of 4 (2 / 4 / 8 / 16 rows per counter round trip measured 8.85 / 8.83 / 8.91 / 9.04 ms per 1M walks; 1 is 50 % slower:
-        // the counter's round trip under contention); launches that give a group only a few dozen walks (a rank's shard of a
-        // strong-scaled batch) end more evenly with 2 (125k walks: 0.985 against 1.006 ms)
-        const int64_t kWorkChunk = total < ngroups * 64 ? 2 : 4;
-        int64_t it = ((int64_t)blockIdx.x * GROUPS + gib) * kWorkChunk;
+        // The counter counts ITEMS: a group takes its first chunk by index, every further one by atomicAdd(counter, chunk) with a
+        // chunk that shrinks as the launch drains -- 4 while more than 8 items per group are left (2 / 4 / 8 / 16 rows per counter
+        // round trip measured 8.85 / 8.83 / 8.91 / 9.04 ms per 1M walks; 1 throughout is 50 % slower: the counter's round trip
+        // under contention), then 2, and 1 for the last two items per group, so that the launch ends within one walk of even
+        // (guided self-scheduling; matters most for launches that give a group only a few dozen walks, e.g. a rank's shard).
+        // (against fixed chunks of 4, or 2 for small launches: 6.80 -> 6.77 ms per 1M walks, 0.951 -> 0.929 ms per 125k)
+        auto chunk_for = [&](int64_t left) -> int64_t { return left > 8 * ngroups ? 4 : (left > 2 * ngroups ? 2 : 1); };
+        const int64_t first = chunk_for(total);
+        int64_t it = ((int64_t)blockIdx.x * GROUPS + gib) * first, end = it + first;
         while (it < total) {
-            const int64_t end = it + kWorkChunk < total ? it + kWorkChunk : total;
+            if (end > total) end = total;
             for (; it < end; ++it) {
                 const int64_t row_rel = a.in_list ? a.in_list[it] : it;
                 if (!do_walk<GS, LdsSpace, (CAP + GS - 1) / GS, PAD>(ws, g, a, row_rel, SV, EL)) {
                     if (g.lane == 0 && a.ovf_list) { uint32_t pos = atomicAdd(a.ovf_count, 1u); a.ovf_list[pos] = row_rel; }
                 }
             }
+            const int64_t chunk = chunk_for(total - it);                 // `it` is close to the counter: the estimate only picks the chunk size
             unsigned long long nxt = 0ull;
-            if (g.lane == 0) nxt = atomicAdd(a.work_next, 1ull);
+            if (g.lane == 0) nxt = atomicAdd(a.work_next, (unsigned long long)chunk);
             const uint32_t lo = g.bcast((uint32_t)nxt, 0), hi = g.bcast((uint32_t)(nxt >> 32), 0);
-            it = (ngroups + (int64_t)(((unsigned long long)hi << 32) | lo)) * kWorkChunk;
+            it = ngroups * first + (int64_t)(((unsigned long long)hi << 32) | lo);
+            end = it + chunk;
         }
         return;
     }
