@@ -933,37 +933,46 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
     STAMP_BEGIN();
     Rng rng;
     rng.init((a.seed_ptr ? *a.seed_ptr : a.seed64) + (uint64_t)i * 0x9e3779b97f4a7c15ull);
+    // Root draw.  The root record is fetched first and the membership hash is reset while it is in flight; the root's row is
+    // requested as soon as the root is known, before the root is entered into the hash and the sample list.
     uint32_t root_vi, root_v;
+    uint32_t j = 0;
+    double u = 0.0;
+    UgsRootRec rr{};
+    int2 vr = make_int2(0, 0);
     if (gd.level == 0) {      // alias draw: two numbers (reference include/sampler.hpp:72-77)
-        uint32_t j = (uint32_t)(rng.next() % (uint64_t)(uint32_t)gd.n);
-        double u = (double)rng.next() * 0x1p-64;   // == / (double)UINT64_MAX (which is 2^64): exact scaling
-        const UgsRootRec rr = P.roots[gd.vbase + j];
-        const bool self = u < rr.prob;
-        root_vi = g.uni(self ? j : (uint32_t)rr.alias);
-        root_v = g.uni((uint32_t)(self ? rr.v_self : rr.v_alias));
+        j = (uint32_t)(rng.next() % (uint64_t)(uint32_t)gd.n);
+        u = (double)rng.next() * 0x1p-64;           // == / (double)UINT64_MAX (which is 2^64): exact scaling
+        rr = P.roots[gd.vbase + j];
     } else {                  // relaxed: uniform over the viable list, one number (reference src/sampler.cpp:169-172)
-        uint32_t idx = (uint32_t)(rng.next() % (uint64_t)(uint32_t)gd.n_viable);
-        int2 vr = P.viable[gd.viable_base + idx];
-        root_vi = g.uni((uint32_t)vr.x);
-        root_v = g.uni((uint32_t)vr.y);
+        const uint32_t idx = (uint32_t)(rng.next() % (uint64_t)(uint32_t)gd.n_viable);
+        vr = P.viable[gd.viable_base + idx];
     }
-    // reset the membership hash (16 bytes per store)
-    {
+    __builtin_amdgcn_sched_barrier(0);
+    {   // reset the membership hash (16 bytes per store)
         uint4 *H4 = reinterpret_cast<uint4 *>(ws.HK);
         const uint32_t n4 = (ws.hmask + 1u) >> 2;
         for (uint32_t s = g.lane; s < n4; s += GS) H4[s] = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
     }
+    if (gd.level == 0) {
+        const bool self = u < rr.prob;
+        root_vi = g.uni(self ? j : (uint32_t)rr.alias);
+        root_v = g.uni((uint32_t)(self ? rr.v_self : rr.v_alias));
+    } else {
+        root_vi = g.uni((uint32_t)vr.x);
+        root_v = g.uni((uint32_t)vr.y);
+    }
+    uint32_t r0 = 0, r1 = 0;
+    int2 e0 = make_int2(0, 0);
+    uint32_t v = root_v;                                                      // the vertex whose row is scanned next (local index size-1)
+    if constexpr (PAD) e0 = load_prow(P, gd.vbase + v, g.lane);
+    else { r0 = g.uni((uint32_t)P.rowptr[gd.rbase + v]); r1 = g.uni((uint32_t)P.rowptr[gd.rbase + v + 1]); }
     SP::sync();
     if (g.lane == 0) { ws.HK[hash_slot(root_v, ws.hmask)] = root_v | kInS; SV[0] = root_v; }
     SP::sync();
     uint32_t size = 1, c = 0, hcount = 1, ecount = 0;
     int nvalid = 0;           // leading stages of the order computation that are still valid
     STAMP_END(0);
-    uint32_t r0 = 0, r1 = 0;
-    int2 e0 = make_int2(0, 0);
-    uint32_t v = root_v;                                                      // the vertex whose row is scanned next (local index size-1)
-    if constexpr (PAD) e0 = load_prow(P, gd.vbase + v, g.lane);
-    else { r0 = g.uni((uint32_t)P.rowptr[gd.rbase + v]); r1 = g.uni((uint32_t)P.rowptr[gd.rbase + v + 1]); }
     for (int step = 0;; ++step) {
         bool ok;
         if (step < k - 1) {                                                   // the last vertex adds no candidates
