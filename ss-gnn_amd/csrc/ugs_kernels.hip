@@ -1290,6 +1290,116 @@ __global__ __launch_bounds__(kScanBlock) void ugs_scan_small(const uint32_t *cou
 // The k adjacency rows of a sample are FLATTENED into one index space e = 0 .. sum(deg)-1 (row-major = the required
 // output order), so every lane's loads are independent: two dependent memory round trips per sample (row bounds, then all
 // adjacency entries) instead of two per sampled vertex.
+// One complete row: its k adjacency rows flattened, membership tested, the hits compacted in (vertex j, CSR position p) order and
+// written with the endpoint numbering of the mode.  The sample's vertices come from the nodes row (`nrow`, batch ids) or, when
+// the caller still has them in LDS, from `SVsrc` (graph-local ids).  SV / PS / R0: group-private LDS scratch.
+template <int GS>
+__device__ __forceinline__ void fill_row(const UgsFillArgs &a, const UgsPlanDev &P, const Grp<GS> &g, const UgsGraphDesc &gd, int64_t row_rel, int64_t i,
+                                         int64_t e0, const int64_t *nrow, const uint32_t *SVsrc, uint32_t *SV, uint32_t *PS, int64_t *R0) {
+    const int k = a.k;
+    const int64_t off = gd.node_lo + a.extra_node_off;
+    LdsSpace::sync();
+    for (int j = g.lane; j < k; j += GS) {
+        const uint32_t u = nrow ? (uint32_t)(nrow[j] - off) : SVsrc[j];
+        const int64_t r0 = P.rowptr[gd.rbase + u], r1 = P.rowptr[gd.rbase + u + 1];
+        SV[j] = u;
+        R0[j] = r0;
+        PS[j + 1] = (uint32_t)(r1 - r0);
+    }
+    LdsSpace::sync();
+    if (g.lane == 0) { uint32_t acc = 0; PS[0] = 0; for (int j = 1; j <= k; ++j) { acc += PS[j]; PS[j] = acc; } }
+    LdsSpace::sync();
+    const uint32_t T = PS[k];
+    int64_t w_off = e0;
+    if (k <= 8) {
+        // the per-row prefix and vertex lists fit in registers: membership and row lookup are compares on registers
+        uint32_t ps[9], sv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { sv[t] = (t < k) ? SV[t] : 0xFFFFFFFEu /* matches no vertex and no idle lane */; ps[t] = (t < k) ? PS[t] : 0xFFFFFFFFu; }
+        ps[8] = 0xFFFFFFFFu;
+        for (uint32_t cb = 0; cb < T; cb += 4 * GS) {
+            uint32_t wv[4];
+            int jj[4], ec[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t e = cb + u * GS + g.lane;
+                wv[u] = kEmpty; jj[u] = 0; ec[u] = 0;
+                if (e < T) {
+                    int j = 0;
+#pragma unroll
+                    for (int t = 1; t < 8; ++t) j += (ps[t] <= e) ? 1 : 0;           // row of flattened entry e
+                    uint32_t base_e = ps[0];
+#pragma unroll
+                    for (int t = 1; t < 8; ++t) base_e = (j == t) ? ps[t] : base_e;
+                    jj[u] = j;
+                    const int2 nb = P.adjf[R0[j] + (int64_t)(e - base_e)];          // neighbour and its edge column together
+                    wv[u] = (uint32_t)nb.x;
+                    ec[u] = nb.y;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (cb + u * GS >= T) break;
+                int l = -1;
+#pragma unroll
+                for (int t = 7; t >= 0; --t) l = (sv[t] == wv[u]) ? t : l;
+                const uint64_t mk = g.ballot(l >= 0);
+                const int64_t pos = w_off + g.below(mk);
+                if (l >= 0 && pos < a.ld) {                           // ld is also the capacity of the caller's edge buffers
+                    const int j = jj[u];
+                    int64_t uf, vf;
+                    if (a.mode == 0) { uf = j; vf = l; }
+                    else if (a.mode == 1) { uf = i * k + j; vf = i * k + l; }
+                    else if (a.mode == 3) { uf = row_rel * k + j; vf = row_rel * k + l; }     // ids into the flattened nodes of THIS call: what the encoder builds (models/ss_gnn.py:463-464)
+                    else { uf = (int64_t)SV[j] + off; vf = (int64_t)SV[l] + off; }
+                    a.edge_index[pos] = uf;
+                    a.edge_index[a.ld + pos] = vf;
+                    a.edge_src[pos] = (int64_t)ec[u];
+                }
+                w_off += __popcll(mk);
+            }
+        }
+        return;
+    }
+    for (uint32_t cb = 0; cb < T; cb += 4 * GS) {
+        uint32_t wv[4];
+        int jj[4], ec[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t e = cb + u * GS + g.lane;
+            wv[u] = kEmpty; jj[u] = 0; ec[u] = 0;
+            if (e < T) {
+                int j = 0;
+                for (int t = 1; t < k; ++t) j += (PS[t] <= e) ? 1 : 0;       // row of flattened entry e
+                jj[u] = j;
+                const int2 nb = P.adjf[R0[j] + (int64_t)(e - PS[j])];
+                wv[u] = (uint32_t)nb.x;
+                ec[u] = nb.y;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (cb + u * GS >= T) break;
+            int l = -1;
+            if (wv[u] != kEmpty) { for (int t = 0; t < k; ++t) if (SV[t] == wv[u]) { l = t; break; } }
+            const uint64_t mk = g.ballot(l >= 0);
+            const int64_t pos = w_off + g.below(mk);
+            if (l >= 0 && pos < a.ld) {
+                const int j = jj[u];
+                int64_t uf, vf;
+                if (a.mode == 0) { uf = j; vf = l; }
+                else if (a.mode == 1) { uf = i * k + j; vf = i * k + l; }
+                else if (a.mode == 3) { uf = row_rel * k + j; vf = row_rel * k + l; }
+                else { uf = (int64_t)SV[j] + off; vf = (int64_t)SV[l] + off; }
+                a.edge_index[pos] = uf;
+                a.edge_index[a.ld + pos] = vf;
+                a.edge_src[pos] = (int64_t)ec[u];
+            }
+            w_off += __popcll(mk);
+        }
+    }
+}
+
 template <int GS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
     constexpr int GROUPS = BLOCK / GS;
@@ -1315,108 +1425,8 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
         if (P.num_graphs == 1) { gi = 0; i = row; }
         else { gi = row / a.m; i = row - gi * a.m; }
         const UgsGraphDesc gd = P.graphs[gi];
-        const int64_t off = gd.node_lo + a.extra_node_off;
         const int64_t *nrow = a.nodes + row_rel * k;
-        LdsSpace::sync();
-        for (int j = g.lane; j < k; j += GS) {
-            const uint32_t u = (uint32_t)(nrow[j] - off);
-            const int64_t r0 = P.rowptr[gd.rbase + u], r1 = P.rowptr[gd.rbase + u + 1];
-            SV[j] = u;
-            R0[j] = r0;
-            PS[j + 1] = (uint32_t)(r1 - r0);
-        }
-        LdsSpace::sync();
-        if (g.lane == 0) { uint32_t acc = 0; PS[0] = 0; for (int j = 1; j <= k; ++j) { acc += PS[j]; PS[j] = acc; } }
-        LdsSpace::sync();
-        const uint32_t T = PS[k];
-        int64_t w_off = e0;
-        if (k <= 8) {
-            // the per-row prefix and vertex lists fit in registers: membership and row lookup are compares on registers
-            uint32_t ps[9], sv[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) { sv[t] = (t < k) ? SV[t] : 0xFFFFFFFEu /* matches no vertex and no idle lane */; ps[t] = (t < k) ? PS[t] : 0xFFFFFFFFu; }
-            ps[8] = 0xFFFFFFFFu;
-            for (uint32_t cb = 0; cb < T; cb += 4 * GS) {
-                uint32_t wv[4];
-                int jj[4], ec[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t e = cb + u * GS + g.lane;
-                    wv[u] = kEmpty; jj[u] = 0; ec[u] = 0;
-                    if (e < T) {
-                        int j = 0;
-#pragma unroll
-                        for (int t = 1; t < 8; ++t) j += (ps[t] <= e) ? 1 : 0;           // row of flattened entry e
-                        uint32_t base_e = ps[0];
-#pragma unroll
-                        for (int t = 1; t < 8; ++t) base_e = (j == t) ? ps[t] : base_e;
-                        jj[u] = j;
-                        const int2 nb = P.adjf[R0[j] + (int64_t)(e - base_e)];          // neighbour and its edge column together
-                        wv[u] = (uint32_t)nb.x;
-                        ec[u] = nb.y;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (cb + u * GS >= T) break;
-                    int l = -1;
-#pragma unroll
-                    for (int t = 7; t >= 0; --t) l = (sv[t] == wv[u]) ? t : l;
-                    const uint64_t mk = g.ballot(l >= 0);
-                    const int64_t pos = w_off + g.below(mk);
-                    if (l >= 0 && pos < a.ld) {                           // ld is also the capacity of the caller's edge buffers
-                        const int j = jj[u];
-                        int64_t uf, vf;
-                        if (a.mode == 0) { uf = j; vf = l; }
-                        else if (a.mode == 1) { uf = i * k + j; vf = i * k + l; }
-                        else if (a.mode == 3) { uf = row_rel * k + j; vf = row_rel * k + l; }     // ids into the flattened nodes of THIS call: what the encoder builds (models/ss_gnn.py:463-464)
-                        else { uf = nrow[j]; vf = nrow[l]; }
-                        a.edge_index[pos] = uf;
-                        a.edge_index[a.ld + pos] = vf;
-                        a.edge_src[pos] = (int64_t)ec[u];
-                    }
-                    w_off += __popcll(mk);
-                }
-            }
-            continue;
-        }
-        for (uint32_t cb = 0; cb < T; cb += 4 * GS) {
-            uint32_t wv[4];
-            int jj[4], ec[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t e = cb + u * GS + g.lane;
-                wv[u] = kEmpty; jj[u] = 0; ec[u] = 0;
-                if (e < T) {
-                    int j = 0;
-                    for (int t = 1; t < k; ++t) j += (PS[t] <= e) ? 1 : 0;       // row of flattened entry e
-                    jj[u] = j;
-                    const int2 nb = P.adjf[R0[j] + (int64_t)(e - PS[j])];
-                    wv[u] = (uint32_t)nb.x;
-                    ec[u] = nb.y;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (cb + u * GS >= T) break;
-                int l = -1;
-                if (wv[u] != kEmpty) { for (int t = 0; t < k; ++t) if (SV[t] == wv[u]) { l = t; break; } }
-                const uint64_t mk = g.ballot(l >= 0);
-                const int64_t pos = w_off + g.below(mk);
-                if (l >= 0 && pos < a.ld) {
-                    const int j = jj[u];
-                    int64_t uf, vf;
-                    if (a.mode == 0) { uf = j; vf = l; }
-                    else if (a.mode == 1) { uf = i * k + j; vf = i * k + l; }
-                    else if (a.mode == 3) { uf = row_rel * k + j; vf = row_rel * k + l; }
-                    else { uf = nrow[j]; vf = nrow[l]; }
-                    a.edge_index[pos] = uf;
-                    a.edge_index[a.ld + pos] = vf;
-                    a.edge_src[pos] = (int64_t)ec[u];
-                }
-                w_off += __popcll(mk);
-            }
-        }
+        fill_row<GS>(a, P, g, gd, row_rel, i, e0, nrow, nullptr, SV, PS, R0);
     }
 }
 
