@@ -35,33 +35,46 @@ __device__ __forceinline__ int64_t edge_offset(const CollateArgs &a, int r) {   
     return off;
 }
 
-// rows: one thread per (rank, local row): nodes row widened, edge_ptr = rank offset + rank-local offset
+// rows: one thread per node ENTRY of a rank (coalesced reads of the narrow ids, coalesced 8-byte stores); the first `rows`
+// threads of a rank also place edge_ptr = rank offset + rank-local offset.  The rank's offset is summed once per block from
+// the message headers.
 __global__ __launch_bounds__(256) void ugs_collate_rows(CollateArgs a) {
+    __shared__ int64_t off_sh;
     const int r = (int)blockIdx.y;
+    if (threadIdx.x == 0) off_sh = edge_offset(a, r);
+    __syncthreads();
+    const int64_t off = off_sh;
     const unsigned char *m = a.msgs + (int64_t)r * a.msg_bytes;
     const int64_t rows = a.row_off[r + 1] - a.row_off[r];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t off = edge_offset(a, r);
-    if (i < rows) {
-        const int64_t gr = a.row_off[r] + i;
-        for (int j = 0; j < a.k; ++j) a.nodes[gr * a.k + j] = widen(m + a.off_nodes, i * a.k + j, a.node_b, true);
-        a.edge_ptr[gr] = off + (int64_t)reinterpret_cast<const uint32_t *>(m + a.off_eptr)[i];
-    }
+    if (i < rows * a.k) a.nodes[a.row_off[r] * a.k + i] = widen(m + a.off_nodes, i, a.node_b, true);
+    if (i < rows) a.edge_ptr[a.row_off[r] + i] = off + (int64_t)reinterpret_cast<const uint32_t *>(m + a.off_eptr)[i];
     if (r == a.world - 1 && i == 0) a.edge_ptr[a.row_off[a.world]] = off + reinterpret_cast<const int64_t *>(m)[1];
 }
 
-// edge entries: one thread per (rank, local entry)
+// edge entries: a block takes 1024 consecutive entries of one rank, four per thread at a stride of 256 (coalesced reads of the
+// narrow wire types, coalesced 8-byte stores)
 __global__ __launch_bounds__(256) void ugs_collate_edges(CollateArgs a) {
+    __shared__ int64_t off_sh;
     const int r = (int)blockIdx.y;
     const unsigned char *m = a.msgs + (int64_t)r * a.msg_bytes;
     const int64_t tot = reinterpret_cast<const int64_t *>(m)[1];
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= tot || e >= a.edge_cap) return;
-    const int64_t pos = edge_offset(a, r) + e;
-    if (pos >= a.ld) return;                                   // ld is also the capacity of the output buffers
-    a.edge_index[pos] = widen(m + a.off_eidx, e, a.eidx_b, a.eidx_b != 1);
-    a.edge_index[a.ld + pos] = widen(m + a.off_eidx, a.edge_cap + e, a.eidx_b, a.eidx_b != 1);
-    a.edge_src[pos] = widen(m + a.off_esrc, e, a.esrc_b, true);
+    const int64_t e_lo = (int64_t)blockIdx.x * 1024;
+    if (e_lo >= tot || e_lo >= a.edge_cap) return;                 // uniform per block
+    if (threadIdx.x == 0) off_sh = edge_offset(a, r);
+    __syncthreads();
+    const int64_t off = off_sh;
+    const bool sgn = a.eidx_b != 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t e = e_lo + q * 256 + threadIdx.x;
+        if (e >= tot || e >= a.edge_cap) continue;
+        const int64_t pos = off + e;
+        if (pos >= a.ld) continue;                                 // ld is also the capacity of the output buffers
+        a.edge_index[pos] = widen(m + a.off_eidx, e, a.eidx_b, sgn);
+        a.edge_index[a.ld + pos] = widen(m + a.off_eidx, a.edge_cap + e, a.eidx_b, sgn);
+        a.edge_src[pos] = widen(m + a.off_esrc, e, a.esrc_b, true);
+    }
 }
 
 }  // namespace
@@ -77,10 +90,10 @@ hipError_t ugs_launch_collate_unpack(const void *d_msgs, int world, int64_t msg_
     a.off_nodes = section_off4[0]; a.off_eptr = section_off4[1]; a.off_eidx = section_off4[2]; a.off_esrc = section_off4[3];
     for (int r = 0; r <= world; ++r) a.row_off[r] = row_off[r];
     a.nodes = d_nodes; a.edge_index = d_edge_index; a.edge_ptr = d_edge_ptr; a.edge_src = d_edge_src; a.ld = ld;
-    const unsigned gx_rows = (unsigned)((rows_cap > 0 ? rows_cap : 1) + 255) / 256;
+    const unsigned gx_rows = (unsigned)(((rows_cap > 0 ? rows_cap : 1) * (int64_t)k + 255) / 256);
     hipLaunchKernelGGL(ugs_collate_rows, dim3(gx_rows, (unsigned)world), dim3(256), 0, s, a);
     if (edge_cap > 0) {
-        const unsigned gx_e = (unsigned)((edge_cap + 255) / 256);
+        const unsigned gx_e = (unsigned)((edge_cap + 1023) / 1024);
         hipLaunchKernelGGL(ugs_collate_edges, dim3(gx_e, (unsigned)world), dim3(256), 0, s, a);
     }
     return hipGetLastError();
