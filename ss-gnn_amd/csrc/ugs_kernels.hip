@@ -475,9 +475,10 @@ __device__ __forceinline__ void stage_mat_reg(const Work<LdsSpace> &ws, const Gr
                                               uint32_t n_old, uint32_t B, uint32_t M, uint32_t S) {
     const uint32_t t = (uint32_t)g.lane;
     const bool valid = t < B;
-    uint32_t pos = t, key = 0u;
-    if (valid && t < n_old) pos = OLD[t];
-    if (valid) key = ws.D[pos];
+    // unpredicated reads (every address lies inside the workspace; what the lanes past the stage read is never used)
+    uint32_t pos = t;
+    if (n_old) { const uint32_t o = OLD[t]; pos = t < n_old ? o : t; }
+    const uint32_t key = ws.D[pos];
     const uint32_t rank = rank_in_registers(g, valid, mod_magic(key, B, M, S), S + 1u);
     if (valid) NEW[rank] = (uint16_t)pos;
     LdsSpace::sync();
@@ -487,9 +488,9 @@ __device__ __forceinline__ Pick stage_final_reg(const Work<LdsSpace> &ws, const 
                                                 uint32_t L, uint32_t B, uint32_t M, uint32_t S, uint32_t rsel) {
     const uint32_t t = (uint32_t)g.lane;
     const bool valid = t < L;
-    uint32_t pos = t, key = 0u;
-    if (valid && t < n_old) pos = OLD[t];
-    if (valid) key = ws.D[pos];
+    uint32_t pos = t;
+    if (n_old) { const uint32_t o = OLD[t]; pos = t < n_old ? o : t; }
+    const uint32_t key = ws.D[pos];
     const uint32_t rank = rank_in_registers(g, valid, mod_magic(key, B, M, S), S + 1u);
     const uint64_t hm = __ballot(rank == rsel) & __ballot(valid);
     const int src = hm ? (__ffsll((long long)hm) - 1) : 0;
@@ -543,11 +544,8 @@ __device__ __forceinline__ void stage_mat_reg2(const Work<LdsSpace> &ws, const G
     const uint32_t t0 = (uint32_t)g.lane, t1 = t0 + 64u;
     const bool valid1 = t1 < B;
     uint32_t pos0 = t0, pos1 = t1;
-    if (t0 < n_old) pos0 = OLD[t0];
-    if (valid1 && t1 < n_old) pos1 = OLD[t1];
-    const uint32_t key0 = ws.D[pos0];
-    uint32_t key1 = 0u;
-    if (valid1) key1 = ws.D[pos1];
+    { const uint32_t o0 = OLD[t0], o1 = OLD[t1]; pos0 = t0 < n_old ? o0 : t0; pos1 = t1 < n_old ? o1 : t1; }
+    const uint32_t key0 = ws.D[pos0], key1 = ws.D[pos1];
     const Rank2 r = rank2_in_registers(g, valid1, mod_magic(key0, B, M, S), mod_magic(key1, B, M, S), S + 1u);
     NEW[r.r0] = (uint16_t)pos0;
     if (valid1) NEW[r.r1] = (uint16_t)pos1;
@@ -557,54 +555,69 @@ __device__ __forceinline__ void stage_mat_reg2(const Work<LdsSpace> &ws, const G
 // The LAST stage only has to name the element at iteration position `rsel`, so nothing is ranked or materialised:
 // one atomicMin (first position of every bucket) and one atomicAdd (its size) on the same word, a scan of the sizes
 // over the bucket leaders to find the bucket that holds position rsel, and ballots among that bucket's few members.
+// Nothing in it is predicated per element (measured on C5: 6.57 -> 6.05 ms per 1M walks against `if (valid[j])` around every
+// read and a valid flag in every test): reads are unconditional (every address lies inside the walk's workspace), an element
+// past the candidates (t >= L) gets bucket number B -- a table slot of its own -- and lanes that hold no candidate at all skip
+// the table atomics (all of them on one address would serialise).  So only the lane holding candidate L-1 enters elements past
+// L; their bucket's first position is the highest of all, it is laid out FIRST and merely shifts every real rank by its size:
+// the search looks for rsel + that size, and no later test asks whether an element is valid.
 template <int GS, int NJ>
 __device__ __forceinline__ Pick stage_final(const Work<LdsSpace> &ws, const Grp<GS> &g, const uint16_t *OLD, uint32_t n_old,
                                             uint32_t L, uint32_t B, uint32_t M, uint32_t S, uint32_t rsel) {
     const uint32_t t0 = (uint32_t)g.lane * NJ;
     uint32_t pos[NJ], bk[NJ];                                                   // position in D; the key is only needed for the bucket
-    bool valid[NJ];
     {
         uint4 *T4 = reinterpret_cast<uint4 *>(ws.TBL);
-        const uint32_t n4 = (B + 3u) >> 2;
+        const uint32_t n4 = (B + 4u) >> 2;                                      // slots 0 .. B
         for (uint32_t i = g.lane; i < n4; i += GS) T4[i] = make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu);
     }
+    // unpredicated reads: every address lies inside the walk's workspace, and what the lanes past the candidates read is not used
+    {
+        uint32_t o[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const uint32_t t = t0 + j;
-        valid[j] = t < L;
-        pos[j] = t;
-        if (valid[j] && t < n_old) pos[j] = OLD[t];
+        for (int j = 0; j < NJ; ++j) o[j] = OLD[t0 + j];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { const uint32_t t = t0 + j; pos[j] = t < n_old ? o[j] : t; }
     }
     {
         uint32_t key[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) { key[j] = 0u; if (valid[j]) key[j] = ws.D[pos[j]]; }
+        for (int j = 0; j < NJ; ++j) key[j] = ws.D[pos[j]];
         LdsSpace::sync();
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            bk[j] = mod_magic(key[j], B, M, S);
-            atomicMin(&ws.TBL[bk[j]], valid[j] ? t0 + j : 0xFFFFu);
+            const uint32_t m = mod_magic(key[j], B, M, S);
+            bk[j] = t0 + j < L ? m : B;
+        }
+        if (t0 < L) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) atomicMin(&ws.TBL[bk[j]], t0 + j);
         }
     }
     LdsSpace::sync();
+    if (t0 < L) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) atomicAdd(&ws.TBL[bk[j]], valid[j] ? 0x10000u : 0u);
+        for (int j = 0; j < NJ; ++j) atomicAdd(&ws.TBL[bk[j]], 0x10000u);
+    }
     LdsSpace::sync();
     uint32_t gs[NJ], mine_total = 0u;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) gs[j] = ws.TBL[bk[j]];                 // (size << 16) | first position
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        gs[j] = (valid[j] && (gs[j] & 0xFFFFu) == t0 + j) ? (gs[j] >> 16) : 0u;
+        gs[j] = (gs[j] & 0xFFFFu) == t0 + j ? (gs[j] >> 16) : 0u;       // bucket leaders carry the size
         mine_total += gs[j];
     }
     const uint32_t incl = g.prefix_incl(mine_total);
     uint32_t run = g.last(incl) - incl;                                   // positions taken by buckets led from higher lanes
+    const uint32_t target = rsel + ((uint32_t)NJ - 1u - (L - 1u) % (uint32_t)NJ);   // only the lane that holds candidate L-1 enters its elements past L
     bool hit = false;
     uint32_t hb = 0u, ho = 0u;
 #pragma unroll
     for (int j = NJ - 1; j >= 0; --j) {
-        if (gs[j] && rsel >= run && rsel < run + gs[j]) { hit = true; hb = bk[j]; ho = rsel - run; }
+        const uint32_t d = target - run;                                  // one unsigned compare: run <= target < run + size
+        const bool h = d < gs[j];
+        hb = h ? bk[j] : hb; ho = h ? d : ho; hit |= h;
         run += gs[j];
     }
     const uint64_t hm = g.ballot(hit);
@@ -612,17 +625,18 @@ __device__ __forceinline__ Pick stage_final(const Work<LdsSpace> &ws, const Grp<
     const uint32_t bstar = g.bcast(hb, hsrc), off = g.bcast(ho, hsrc);
     // members of that bucket are visited in DESCENDING position: the answer has exactly `off` members above it.  Members in
     // higher lanes: the lane's own member count, suffix-summed over the lanes by ONE scan (not one ballot per element slot)
-    bool cand[NJ];
-    uint32_t own = 0u;
+    uint32_t cj[NJ], own = 0u;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) { cand[j] = valid[j] && bk[j] == bstar; own += cand[j] ? 1u : 0u; }
+    for (int j = 0; j < NJ; ++j) { cj[j] = bk[j] == bstar ? 1u : 0u; own += cj[j]; }
     const uint32_t oincl = g.prefix_incl(own);
-    const uint32_t higher = g.last(oincl) - oincl;
+    uint32_t above = g.last(oincl) - oincl;
     bool have = false;
-    uint32_t mine = 0u, own_above = 0u;
+    uint32_t mine = 0u;
 #pragma unroll
     for (int j = NJ - 1; j >= 0; --j) {
-        if (cand[j]) { if (higher + own_above == off) { have = true; mine = pos[j]; } own_above += 1u; }
+        const bool h = cj[j] != 0u && above == off;
+        mine = h ? pos[j] : mine; have |= h;
+        above += cj[j];
     }
     const uint64_t mk = g.ballot(have);
     const int src = mk ? (__ffsll((long long)mk) - 1) : 0;
@@ -692,11 +706,12 @@ __device__ __forceinline__ Pick final_at(const Work<LdsSpace> &ws, const Grp<GS>
     return Pick{0u, 0u};
 }
 
+// the stages to compute come as a bit set: one scalar bit test and branch per stage
 template <int GS, int MAXPER, int STAGE, int NST>
-__device__ __forceinline__ void materialise_from(const Work<LdsSpace> &ws, const Grp<GS> &g, int fs, int &nvalid) {
+__device__ __forceinline__ void materialise_bits(const Work<LdsSpace> &ws, const Grp<GS> &g, uint32_t need) {
     if constexpr (STAGE < NST) {
-        if (nvalid <= STAGE && STAGE < fs) { mat_at<GS, MAXPER, STAGE>(ws, g); nvalid = STAGE + 1; }
-        materialise_from<GS, MAXPER, STAGE + 1, NST>(ws, g, fs, nvalid);
+        if (need & (1u << STAGE)) mat_at<GS, MAXPER, STAGE>(ws, g);
+        materialise_bits<GS, MAXPER, STAGE + 1, NST>(ws, g, need);
     }
 }
 
@@ -711,17 +726,21 @@ __device__ __forceinline__ Pick final_from(const Work<LdsSpace> &ws, const Grp<G
 }
 
 template <int NST> __device__ __forceinline__ int chain_index_below(uint32_t x) {     // number of the first NST chain values < x
-    int n = 0;
+    // x <= 2^16: the sign bit of B[i] - x says x > B[i] -- two scalar instructions per term and no condition codes (the
+    // compare-and-add form went through a lane mask and a VGPR per term: 6.77 -> 6.61 ms per 1M walks together with the
+    // bit-set dispatch of materialise_bits)
+    uint32_t n = 0;
 #pragma unroll
-    for (int i = 0; i < NST; ++i) n += (kChainHost[i] < x) ? 1 : 0;
-    return n;
+    for (int i = 0; i < NST; ++i) n += (kChainHost[i] - x) >> 31;
+    return (int)n;
 }
 
 template <int GS, int MAXPER>
 __device__ __forceinline__ Pick select_lds(const Work<LdsSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel, int &nvalid) {
     constexpr int NST = nst_of(MAXPER * GS);
     const int fs = chain_index_below<NST>(c);                                 // the final stage: first chain value >= c
-    materialise_from<GS, MAXPER, 0, NST>(ws, g, fs, nvalid);
+    materialise_bits<GS, MAXPER, 0, NST>(ws, g, ((1u << fs) - 1u) & ~((1u << nvalid) - 1u));     // stages nvalid .. fs-1
+    nvalid = nvalid > fs ? nvalid : fs;
     return final_from<GS, MAXPER, 0, NST>(ws, g, fs, c, rsel);
 }
 
