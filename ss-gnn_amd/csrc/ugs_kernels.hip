@@ -25,10 +25,10 @@
 //     D, so the final stage names the chosen candidate's position and D is never searched -- valid across growth steps while
 //     the removed candidate lies behind the prefix it covers.  The last stage materialises nothing:
 //     the bucket holding position rng % |cut| is found by the scan and the element inside it by ballots (stage_final).
-//     Materialising stages of up to 128 elements and final stages of up to 64 (one walk per wave) never touch the bucket
-//     table: a radix pass of ballots gives every lane the mask of its bucket-mates and popcounts do the rest
-//     (rank_in_registers / rank2_in_registers).  In the LDS tiers the stage index is a template parameter, so the chain
-//     constants are immediates (mat_at / final_at).
+//     Materialising and final stages of up to 64 elements (one walk per wave) never touch the bucket table: a radix pass of
+//     ballots gives every lane the mask of its bucket-mates and popcounts do the rest (rank_in_registers); stages of 65..128
+//     elements get the same masks from a 128-bit member mask per bucket in LDS (mates2_by_table).  In the LDS tiers the stage
+//     index is a template parameter, so the chain constants are immediates (mat_at / final_at).
 //     (The global-memory fallback tier keeps the simpler "peel round" formulation, select_in_order.)
 //   * the neighbour's order rank is stored next to the neighbour id in HBM (int2 adjacency), so the suffix filter is
 //     free; root records pack the alias row and both candidate root vertices in 24 bytes; the one-walk-per-wave tiers read
@@ -110,23 +110,63 @@ __device__ __forceinline__ uint32_t mod_magic(uint32_t x, uint32_t B, uint32_t M
 }
 
 // x mod c for a 64-bit x and a small divisor (c < 2^16), exact, in 32-bit operations: with hi/lo the halves of x,
-// x mod c = ((hi mod c) * (2^32 mod c) + lo mod c) mod c, every product below 2^32.  One 32-bit division gives
-// M = floor((2^32 - 1) / c); floor(y * M / 2^32) undershoots floor(y / c) by at most 2, hence the two corrections.
-// The generic 64-bit remainder costs ~150 instructions per draw; this is a third of that.
+// x mod c = ((hi mod c) * (2^32 mod c) + lo mod c) mod c, every product below 2^32.  With M = floor((2^32 - 1) / c),
+// floor(y * M / 2^32) is floor(y / c) or one less (2^32 - c M <= c, so the estimate falls short by y c / (c 2^32) < 1): one
+// correction.  The generic 64-bit remainder costs ~150 instructions per draw.
 __device__ __forceinline__ uint32_t mod_small(uint32_t y, uint32_t c, uint32_t M) {
-    uint32_t r = y - __umulhi(y, M) * c;
-    r = r >= c ? r - c : r;
-    r = r >= c ? r - c : r;
-    return r;
+    const uint32_t r = y - __umulhi(y, M) * c;
+    const uint32_t r2 = r - c;                          // wraps when r < c: the minimum is the corrected remainder
+    return r < r2 ? r : r2;
 }
-template <bool SMALL>       // SMALL: the caller guarantees c < 2^16 (every LDS tier: c <= its candidate capacity)
+__device__ __forceinline__ uint32_t mod64_with(uint64_t x, uint32_t c, uint32_t M, uint32_t r32 /* 2^32 mod c */) {
+    const uint32_t hm = mod_small((uint32_t)(x >> 32), c, M), lm = mod_small((uint32_t)x, c, M);
+    return mod_small(hm * r32 + lm, c, M);
+}
+// (M, 2^32 mod c) for c <= 2048: with one walk per wave the candidate count is wave-uniform, so the per-step draw fetches its
+// constants with one scalar load instead of a 32-bit division (entry 0 is never used)
+constexpr int kRecipMax = 2048;
+struct RecipTab { uint2 e[kRecipMax + 1]; };
+constexpr RecipTab make_recip() {
+    RecipTab t{};
+    t.e[0] = uint2{0u, 0u};
+    for (uint32_t c = 1; c <= (uint32_t)kRecipMax; ++c) {
+        const uint32_t M = 0xFFFFFFFFu / c;
+        uint32_t r32 = 0xFFFFFFFFu - M * c + 1u;
+        if (r32 == c) r32 = 0u;
+        t.e[c] = uint2{M, r32};
+    }
+    return t;
+}
+__constant__ RecipTab d_recip = make_recip();
+
+// SMALL: the caller guarantees c < 2^16 (every LDS tier: c <= its candidate capacity); TABLE: c <= kRecipMax and wave-uniform
+template <bool SMALL, bool TABLE = false>
 __device__ __forceinline__ uint32_t mod64_by(uint64_t x, uint32_t c) {
+    if constexpr (TABLE) {
+        const uint2 e = d_recip.e[c];
+        return mod64_with(x, c, e.x, e.y);
+    }
     if constexpr (!SMALL) { if (c >= 65536u) return (uint32_t)(x % (uint64_t)c); }
     const uint32_t M = 0xFFFFFFFFu / c;
     uint32_t r32 = 0xFFFFFFFFu - M * c + 1u;            // (2^32 - 1) mod c + 1, in [1, c]
     r32 = r32 == c ? 0u : r32;                          // 2^32 mod c
-    const uint32_t hm = mod_small((uint32_t)(x >> 32), c, M), lm = mod_small((uint32_t)x, c, M);
-    return mod_small(hm * r32 + lm, c, M);
+    return mod64_with(x, c, M, r32);
+}
+
+// x mod n for the root draw (n = vertices of the graph, < 2^31).  Small graphs take the exact 32-bit route above; for n >= 2^16
+// the quotient is estimated in double precision -- x and x / n are each rounded once (relative error 2^-53 each, x / n < 2^48),
+// so the estimate is off by at most one -- and the remainder is corrected in integers (two corrections each way).  A third of
+// the generic 64-bit remainder's instructions.
+__device__ __forceinline__ uint32_t mod64_root(uint64_t x, uint32_t n) {
+    if (n < 65536u) return mod64_by<true>(x, n);
+    const double q_est = floor((double)x / (double)n);
+    const uint64_t q = (uint64_t)q_est;
+    int64_t r = (int64_t)(x - q * (uint64_t)n);        // exact modulo 2^64; the true value lies in (-2n, 3n)
+    r = r < 0 ? r + (int64_t)n : r;
+    r = r < 0 ? r + (int64_t)n : r;
+    r = r >= (int64_t)n ? r - (int64_t)n : r;
+    r = r >= (int64_t)n ? r - (int64_t)n : r;
+    return (uint32_t)r;
 }
 
 // xorshift64* (reference include/sampler.hpp:26-36)
@@ -501,19 +541,26 @@ __device__ __forceinline__ Pick stage_final_reg(const Work<LdsSpace> &ws, const 
 // slot).  Positions are slot-major, so a bucket's leader is in slot 0 whenever it has a member there, and the buckets led
 // from slot 1 (the later positions) are laid out first.
 struct Rank2 { uint32_t r0, r1; };
-__device__ __forceinline__ Rank2 rank2_in_registers(const Grp<64> &g, bool valid1, uint32_t bk0, uint32_t bk1, uint32_t nbits) {
-    const uint64_t v1 = __ballot(valid1);
-    const uint32_t v1l = (uint32_t)v1, v1h = (uint32_t)(v1 >> 32);
-    uint32_t a00 = ~0u, b00 = ~0u, a01 = v1l, b01 = v1h, a10 = ~0u, b10 = ~0u, a11 = v1l, b11 = v1h;   // (low, high) halves; slot 0 is full
-    for (uint32_t bit = 0; bit < nbits; ++bit) {
-        const uint32_t x0 = spread_bit(bk0, bit), x1 = spread_bit(bk1, bit);
-        const uint64_t q0 = __ballot(x0 != 0u), q1 = __ballot(x1 != 0u);
-        const uint32_t q0l = (uint32_t)q0, q0h = (uint32_t)(q0 >> 32), q1l = (uint32_t)q1, q1h = (uint32_t)(q1 >> 32);
-        a00 &= ~(q0l ^ x0); b00 &= ~(q0h ^ x0);  a01 &= ~(q1l ^ x0); b01 &= ~(q1h ^ x0);
-        a10 &= ~(q0l ^ x1); b10 &= ~(q0h ^ x1);  a11 &= ~(q1l ^ x1); b11 &= ~(q1h ^ x1);
-    }
-    const uint64_t m00 = ((uint64_t)b00 << 32) | a00, m01 = ((uint64_t)b01 << 32) | a01;
-    const uint64_t m10 = ((uint64_t)b10 << 32) | a10, m11 = ((uint64_t)b11 << 32) | a11;
+// The four mate masks come through the bucket table: every bucket owns a 128-bit member mask (bit l of word s: the element of
+// lane l in slot s), elements set their bit with one 64-bit LDS atomic OR and read their bucket's mask back -- two LDS round
+// trips in place of a radix pass of ballots, 12 vector instructions per bit of the bucket number (stage of 127 elements: 208 ->
+// 90 vector instructions, 6.05 -> 5.79 ms per 1M walks on C5; for the one-element-per-lane stages the same exchange is neutral
+// -- 62-78 -> 37-41 instructions against two more LDS round trips -- and they keep the ballots)
+__device__ __forceinline__ void mates2_by_table(uint32_t *TBL, const Grp<64> &g, bool valid1, uint32_t bk0, uint32_t bk1, uint32_t B,
+                                                uint64_t &m00, uint64_t &m01, uint64_t &m10, uint64_t &m11) {
+    uint4 *T4 = reinterpret_cast<uint4 *>(TBL);
+    for (uint32_t i = (uint32_t)g.lane; i < B; i += 64) T4[i] = make_uint4(0u, 0u, 0u, 0u);
+    LdsSpace::sync();
+    unsigned long long *T8 = reinterpret_cast<unsigned long long *>(TBL);
+    const unsigned long long bit = 1ull << g.lane;
+    atomicOr(&T8[2u * bk0], bit);
+    if (valid1) atomicOr(&T8[2u * bk1 + 1u], bit);
+    LdsSpace::sync();
+    const uint4 a = T4[bk0], b = T4[bk1];
+    m00 = ((uint64_t)a.y << 32) | a.x; m01 = ((uint64_t)a.w << 32) | a.z;
+    m10 = ((uint64_t)b.y << 32) | b.x; m11 = ((uint64_t)b.w << 32) | b.z;
+}
+__device__ __forceinline__ Rank2 rank2_from_mates(const Grp<64> &g, bool valid1, uint64_t m00, uint64_t m01, uint64_t m10, uint64_t m11) {
     const uint64_t gt = ~1ull << g.lane;
     const uint32_t lane = (uint32_t)g.lane;
     // element in slot 0: its bucket's leader is the lowest slot-0 mate (itself included)
@@ -546,7 +593,9 @@ __device__ __forceinline__ void stage_mat_reg2(const Work<LdsSpace> &ws, const G
     uint32_t pos0 = t0, pos1 = t1;
     { const uint32_t o0 = OLD[t0], o1 = OLD[t1]; pos0 = t0 < n_old ? o0 : t0; pos1 = t1 < n_old ? o1 : t1; }
     const uint32_t key0 = ws.D[pos0], key1 = ws.D[pos1];
-    const Rank2 r = rank2_in_registers(g, valid1, mod_magic(key0, B, M, S), mod_magic(key1, B, M, S), S + 1u);
+    uint64_t m00, m01, m10, m11;
+    mates2_by_table(ws.TBL, g, valid1, mod_magic(key0, B, M, S), valid1 ? mod_magic(key1, B, M, S) : 0u, B, m00, m01, m10, m11);
+    const Rank2 r = rank2_from_mates(g, valid1, m00, m01, m10, m11);
     NEW[r.r0] = (uint16_t)pos0;
     if (valid1) NEW[r.r1] = (uint16_t)pos1;
     LdsSpace::sync();
@@ -960,11 +1009,11 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
     UgsRootRec rr{};
     int2 vr = make_int2(0, 0);
     if (gd.level == 0) {      // alias draw: two numbers (reference include/sampler.hpp:72-77)
-        j = (uint32_t)(rng.next() % (uint64_t)(uint32_t)gd.n);
+        j = mod64_root(rng.next(), (uint32_t)gd.n);
         u = (double)rng.next() * 0x1p-64;           // == / (double)UINT64_MAX (which is 2^64): exact scaling
         rr = P.roots[gd.vbase + j];
     } else {                  // relaxed: uniform over the viable list, one number (reference src/sampler.cpp:169-172)
-        const uint32_t idx = (uint32_t)(rng.next() % (uint64_t)(uint32_t)gd.n_viable);
+        const uint32_t idx = mod64_root(rng.next(), (uint32_t)gd.n_viable);
         vr = P.viable[gd.viable_base + idx];
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1004,7 +1053,7 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
         STAMP_END(1);
         if (!ok) return false;
         if (step >= k - 1 || c == 0) break;                                   // complete, or growth failed: partial row
-        const uint32_t rsel = g.uni(mod64_by<sizeof(typename SP::TW) == 4>(rng.next(), c));
+        const uint32_t rsel = g.uni(mod64_by<sizeof(typename SP::TW) == 4, sizeof(typename SP::TW) == 4 && GS == 64>(rng.next(), c));
         STAMP_END(4);
         const Pick pick = select_any<GS, MAXPER>(ws, g, c, rsel, nvalid);
         const uint32_t w = pick.w;
@@ -1098,6 +1147,7 @@ template <int CAP> struct TierCfg {
     static constexpr int BCAP_A = (BCAP + 3) & ~3;
     static constexpr int HS = CAP <= 64 ? 128 : (CAP <= 512 ? 512 : (CAP <= 1024 ? 2048 : 4096));
     static constexpr int HLIMIT = CAP <= 512 && CAP > 64 ? HS / 8 * 7 : HS / 4 * 3;   // max distinct vertices a walk may have seen
+    static_assert(CAP <= 64 || BCAP_A * 4 >= 127 * 16, "mates2_by_table keeps 16 bytes per bucket of the 127-bucket stage in TBL");
     static_assert(HLIMIT == UGS_TIER_HASH_LIMIT[CAP <= 64 ? 0 : (CAP <= 512 ? 1 : (CAP <= 1024 ? 2 : 3))], "host tier logic (choose_tier) relies on this limit");
     static constexpr int ELW = CAP > 64 ? 4 * UGS_STAGE_ENTRIES : 0;             // staged hits (one-walk-per-wave tiers)
     static constexpr int WORDS = CAP /*D*/ + ORDW + BCAP_A /*TBL*/ + HS /*HK*/ + UGS_KMAX /*SV*/ + ELW;
