@@ -108,6 +108,7 @@ __device__ __forceinline__ uint32_t mod_magic(uint32_t x, uint32_t B, uint32_t M
     uint32_t q = __umulhi(x, M) >> S;
     return x - q * B;
 }
+__device__ __forceinline__ uint32_t mod_stage(uint32_t x, uint32_t B, uint32_t M, uint32_t S) { return mod_magic(x, B, M, S); }
 
 // x mod c for a 64-bit x and a small divisor (c < 2^16), exact, in 32-bit operations: with hi/lo the halves of x,
 // x mod c = ((hi mod c) * (2^32 mod c) + lo mod c) mod c, every product below 2^32.  With M = floor((2^32 - 1) / c),
@@ -421,7 +422,7 @@ __device__ __forceinline__ void stage_mat(const Work<LdsSpace> &ws, const Grp<GS
     LdsSpace::sync();
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        bk[j] = mod_magic(key[j], B, M, S);
+        bk[j] = mod_stage(key[j], B, M, S);
         atomicMin(&ws.TBL[bk[j]], valid[j] ? t0 + j : 0xFFFFu);
     }
     LdsSpace::sync();
@@ -519,7 +520,7 @@ __device__ __forceinline__ void stage_mat_reg(const Work<LdsSpace> &ws, const Gr
     uint32_t pos = t;
     if (n_old) { const uint32_t o = OLD[t]; pos = t < n_old ? o : t; }
     const uint32_t key = ws.D[pos];
-    const uint32_t rank = rank_in_registers(g, valid, mod_magic(key, B, M, S), S + 1u);
+    const uint32_t rank = rank_in_registers(g, valid, mod_stage(key, B, M, S), S + 1u);
     if (valid) NEW[rank] = (uint16_t)pos;
     LdsSpace::sync();
 }
@@ -531,7 +532,7 @@ __device__ __forceinline__ Pick stage_final_reg(const Work<LdsSpace> &ws, const 
     uint32_t pos = t;
     if (n_old) { const uint32_t o = OLD[t]; pos = t < n_old ? o : t; }
     const uint32_t key = ws.D[pos];
-    const uint32_t rank = rank_in_registers(g, valid, mod_magic(key, B, M, S), S + 1u);
+    const uint32_t rank = rank_in_registers(g, valid, mod_stage(key, B, M, S), S + 1u);
     const uint64_t hm = __ballot(rank == rsel) & __ballot(valid);
     const int src = hm ? (__ffsll((long long)hm) - 1) : 0;
     return Pick{g.bcast(key, src), g.bcast(pos, src)};
@@ -594,7 +595,7 @@ __device__ __forceinline__ void stage_mat_reg2(const Work<LdsSpace> &ws, const G
     { const uint32_t o0 = OLD[t0], o1 = OLD[t1]; pos0 = t0 < n_old ? o0 : t0; pos1 = t1 < n_old ? o1 : t1; }
     const uint32_t key0 = ws.D[pos0], key1 = ws.D[pos1];
     uint64_t m00, m01, m10, m11;
-    mates2_by_table(ws.TBL, g, valid1, mod_magic(key0, B, M, S), valid1 ? mod_magic(key1, B, M, S) : 0u, B, m00, m01, m10, m11);
+    mates2_by_table(ws.TBL, g, valid1, mod_stage(key0, B, M, S), valid1 ? mod_stage(key1, B, M, S) : 0u, B, m00, m01, m10, m11);
     const Rank2 r = rank2_from_mates(g, valid1, m00, m01, m10, m11);
     NEW[r.r0] = (uint16_t)pos0;
     if (valid1) NEW[r.r1] = (uint16_t)pos1;
@@ -635,7 +636,7 @@ __device__ __forceinline__ Pick stage_final(const Work<LdsSpace> &ws, const Grp<
         LdsSpace::sync();
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const uint32_t m = mod_magic(key[j], B, M, S);
+            const uint32_t m = mod_stage(key[j], B, M, S);
             bk[j] = t0 + j < L ? m : B;
         }
         if (t0 < L) {
@@ -785,8 +786,14 @@ template <int NST> __device__ __forceinline__ int chain_index_below(uint32_t x) 
 }
 
 template <int GS, int MAXPER>
-__device__ __forceinline__ Pick select_lds(const Work<LdsSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel, int &nvalid) {
+__device__ __forceinline__ Pick select_lds(const Work<LdsSpace> &ws, const Grp<GS> &g_, uint32_t c, uint32_t rsel, int &nvalid) {
     constexpr int NST = nst_of(MAXPER * GS);
+    // The stages address LDS by lane * (elements per lane) and compare the lane with constants; the compiler hoists all of that
+    // out of the walk loops, runs out of registers and reloads it from scratch memory right where a stage starts (a memory
+    // round trip in front of its first LDS read).  An opaque copy of the lane index keeps those few instructions inside
+    // (C5: 96 VGPRs + 52 bytes of scratch -> 88 VGPRs, none; 5.68 -> 5.53 ms per 1M walks).
+    Grp<GS> g = g_;
+    asm volatile("" : "+v"(g.lane));
     const int fs = chain_index_below<NST>(c);                                 // the final stage: first chain value >= c
     materialise_bits<GS, MAXPER, 0, NST>(ws, g, ((1u << fs) - 1u) & ~((1u << nvalid) - 1u));     // stages nvalid .. fs-1
     nvalid = nvalid > fs ? nvalid : fs;
@@ -978,9 +985,10 @@ __device__ __forceinline__ void stage_flush(uint32_t ne, const Grp<64> &g, const
 
 // One walk.  Returns false on workspace overflow (the row is then redone by the next tier).
 template <int GS, class SP, int MAXPER, bool PAD>
-__device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, const UgsWalkArgs &a, int64_t row_rel,
+__device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, const UgsWalkArgs &a, int64_t row_rel,
                                         uint32_t *SV /* [UGS_KMAX] group-private */, uint4 *EL /* [UGS_STAGE_ENTRIES] or null */) {
     static_assert(!PAD || GS == 64, "padded rows are read by a whole wave");
+    const Grp<GS> &g = g_;
     constexpr bool STG = GS == 64 && sizeof(typename SP::TW) == 4;             // one walk per wave, LDS workspace
     StageCtx sc;
     sc.EL = EL; sc.ne = 0u; sc.on = STG && a.stage != nullptr && EL != nullptr;
@@ -1042,6 +1050,8 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
     int nvalid = 0;           // leading stages of the order computation that are still valid
     STAMP_END(0);
     for (int step = 0;; ++step) {
+        Grp<GS> g = g_;                                                       // see select_lds: keeps lane-derived constants out of long-lived registers
+        if constexpr (GS == 64) asm volatile("" : "+v"(g.lane));
         bool ok;
         if (step < k - 1) {                                                   // the last vertex adds no candidates
             if constexpr (PAD) ok = scan_prow<SP, true, STG>(ws, g, P, v, root_vi, size, c, hcount, ecount, e0, gd.vbase + v, sc);
@@ -1083,11 +1093,21 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g, co
         STAMP_END(7);
         for (uint32_t t0 = q; t0 + 1 < c; t0 += 4 * GS) {
             uint32_t x[4];
+            if constexpr (sizeof(typename SP::TW) == 4) {
+                // LDS tiers: nothing predicated.  Reads past the candidates stay inside the walk's workspace (the order arrays and
+                // the bucket table follow D); writes past the new end land in dead slots of D (index clamped to its last one).
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const uint32_t t = t0 + u * GS + g.lane; x[u] = (t + 1 < c) ? ws.D[t + 1] : 0u; }
-            SP::sync();
+                for (int u = 0; u < 4; ++u) x[u] = ws.D[t0 + u * GS + g.lane + 1];
+                SP::sync();
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const uint32_t t = t0 + u * GS + g.lane; if (t + 1 < c) ws.D[t] = x[u]; }
+                for (int u = 0; u < 4; ++u) { const uint32_t t = t0 + u * GS + g.lane; ws.D[t < ws.cap - 1u ? t : ws.cap - 1u] = x[u]; }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const uint32_t t = t0 + u * GS + g.lane; x[u] = (t + 1 < c) ? ws.D[t + 1] : 0u; }
+                SP::sync();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const uint32_t t = t0 + u * GS + g.lane; if (t + 1 < c) ws.D[t] = x[u]; }
+            }
             SP::sync();
         }
         {   // stages whose candidates all precede position q keep their order
