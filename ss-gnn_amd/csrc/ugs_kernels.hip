@@ -1144,7 +1144,7 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
     uint32_t ecol = 0u;
     if constexpr (STG) {
         flush = sc.on && nedges != 0u && sc.ne <= UGS_STAGE_ENTRIES;
-        if (flush && (uint32_t)g.lane < sc.ne) { en = sc.EL[g.lane]; ecol = (uint32_t)P.adjf[en.x].y; }
+                if (flush && (uint32_t)g.lane < sc.ne) { en = sc.EL[g.lane]; ecol = (uint32_t)P.adjf[en.x].y; }
     }
     // nodes row: growth order, -1 padded (reference src/sampler.cpp:205-216, src/ugs_sampler_batch_extension.cpp:188-196)
     const int64_t off = gd.node_lo + a.extra_node_off;
