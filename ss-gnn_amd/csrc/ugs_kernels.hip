@@ -25,10 +25,10 @@
 //     D, so the final stage names the chosen candidate's position and D is never searched -- valid across growth steps while
 //     the removed candidate lies behind the prefix it covers.  The last stage materialises nothing:
 //     the bucket holding position rng % |cut| is found by the scan and the element inside it by ballots (stage_final).
-//     Materialising and final stages of up to 64 elements (one walk per wave) never touch the bucket table: a radix pass of
-//     ballots gives every lane the mask of its bucket-mates and popcounts do the rest (rank_in_registers); stages of 65..128
-//     elements get the same masks from a 128-bit member mask per bucket in LDS (mates2_by_table).  In the LDS tiers the stage
-//     index is a template parameter, so the chain constants are immediates (mat_at / final_at).
+//     Materialising stages of up to 128 elements and final stages of up to 64 (one walk per wave) rank every element in
+//     registers: a member mask per bucket in LDS (one atomic OR, one read) gives every lane the mask of its bucket-mates and
+//     popcounts do the rest (rank_in_registers, mates2_by_table).  In the LDS tiers the stage index is a template parameter,
+//     so the chain constants are immediates (mat_at / final_at).
 //     (The global-memory fallback tier keeps the simpler "peel round" formulation, select_in_order.)
 //   * the neighbour's order rank is stored next to the neighbour id in HBM (int2 adjacency), so the suffix filter is
 //     free; root records pack the alias row and both candidate root vertices in 24 bytes; the one-walk-per-wave tiers read
@@ -482,26 +482,23 @@ __device__ __forceinline__ void stage_mat(const Work<LdsSpace> &ws, const Grp<GS
     LdsSpace::sync();
 }
 
-// Stages of at most 64 elements with one walk per wave: ONE element per lane and no bucket table at all.  A radix pass of
-// ballots over the bits of the bucket number leaves every lane with the 64-bit mask of the lanes that share its bucket;
+// Stages of at most 64 elements with one walk per wave: ONE element per lane.  Every lane gets the 64-bit mask of the lanes
+// that share its bucket (through a member mask per bucket in LDS, see rank_in_registers);
 // popcounts of that mask give the bucket's size, its first position (the leader) and the number of members above the lane,
 // one DPP scan of the sizes over the leaders gives every bucket's start and one ds_bpermute fetches the leader's start.
-// rank = start + members above -- the same definition as stage_mat, with no LDS traffic except the element itself.
-__device__ __forceinline__ uint32_t spread_bit(uint32_t v, uint32_t bit) {     // 0 or 0xFFFFFFFF (v_bfe_i32)
-    return (uint32_t)((int32_t)(v << (31u - bit)) >> 31);
-}
+// rank = start + members above -- the same definition as stage_mat.
 
-__device__ __forceinline__ uint32_t rank_in_registers(const Grp<64> &g, bool valid, uint32_t bk, uint32_t nbits) {
-    // mates &= (own bit set ? b : ~b), written per 32-bit half as m & ~(b ^ x) with x = 0 / ~0: one v_bitop3_b32 each
-    const uint64_t v = __ballot(valid);
-    uint32_t mlo = (uint32_t)v, mhi = (uint32_t)(v >> 32);
-    for (uint32_t bit = 0; bit < nbits; ++bit) {
-        const uint32_t x = spread_bit(bk, bit);
-        const uint64_t b = __ballot(x != 0u);
-        mlo &= ~((uint32_t)b ^ x);
-        mhi &= ~((uint32_t)(b >> 32) ^ x);
-    }
-    const uint64_t mates = ((uint64_t)mhi << 32) | mlo;
+__device__ __forceinline__ uint32_t rank_in_registers(const Grp<64> &g, bool valid, uint32_t bk, uint32_t *TBL, uint32_t B) {
+    // mask of the lane's bucket-mates through the (otherwise idle) bucket table: one 64-bit member mask per bucket, set by an
+    // LDS atomic OR and read back -- one LDS round trip in place of a radix pass of ballots over the bits of the bucket number
+    // (4 vector instructions per bit: 62-78 -> 37-41 per stage).  B <= 127: a final of <= 64 candidates may have 127 buckets.
+    // (Neutral while the kernel still spent its time elsewhere, -3.3 % once the order stages dominated: 5.45 -> 5.27 ms.)
+    unsigned long long *T8 = reinterpret_cast<unsigned long long *>(TBL);
+    for (uint32_t i = (uint32_t)g.lane; i < B; i += 64) T8[i] = 0ull;
+    LdsSpace::sync();
+    if (valid) atomicOr(&T8[bk], 1ull << g.lane);
+    LdsSpace::sync();
+    const uint64_t mates = T8[bk];
     const uint32_t size = (uint32_t)__popcll(mates);
     const uint32_t first = valid ? (uint32_t)(__ffsll((long long)mates) - 1) : (uint32_t)g.lane;
     const uint32_t above = (uint32_t)__popcll(mates & (~1ull << g.lane));
@@ -520,7 +517,7 @@ __device__ __forceinline__ void stage_mat_reg(const Work<LdsSpace> &ws, const Gr
     uint32_t pos = t;
     if (n_old) { const uint32_t o = OLD[t]; pos = t < n_old ? o : t; }
     const uint32_t key = ws.D[pos];
-    const uint32_t rank = rank_in_registers(g, valid, mod_stage(key, B, M, S), S + 1u);
+    const uint32_t rank = rank_in_registers(g, valid, mod_stage(key, B, M, S), ws.TBL, B);
     if (valid) NEW[rank] = (uint16_t)pos;
     LdsSpace::sync();
 }
@@ -532,7 +529,7 @@ __device__ __forceinline__ Pick stage_final_reg(const Work<LdsSpace> &ws, const 
     uint32_t pos = t;
     if (n_old) { const uint32_t o = OLD[t]; pos = t < n_old ? o : t; }
     const uint32_t key = ws.D[pos];
-    const uint32_t rank = rank_in_registers(g, valid, mod_stage(key, B, M, S), S + 1u);
+    const uint32_t rank = rank_in_registers(g, valid, mod_stage(key, B, M, S), ws.TBL, B);
     const uint64_t hm = __ballot(rank == rsel) & __ballot(valid);
     const int src = hm ? (__ffsll((long long)hm) - 1) : 0;
     return Pick{g.bcast(key, src), g.bcast(pos, src)};
