@@ -494,7 +494,8 @@ __device__ __forceinline__ uint32_t rank_in_registers(const Grp<64> &g, bool val
     // (4 vector instructions per bit: 62-78 -> 37-41 per stage).  B <= 127: a final of <= 64 candidates may have 127 buckets.
     // (Neutral while the kernel still spent its time elsewhere, -3.3 % once the order stages dominated: 5.45 -> 5.27 ms.)
     unsigned long long *T8 = reinterpret_cast<unsigned long long *>(TBL);
-    for (uint32_t i = (uint32_t)g.lane; i < B; i += 64) T8[i] = 0ull;
+    T8[g.lane] = 0ull;                                                       // all 64 lanes: the table has room for 128 masks
+    if (B > 64u) T8[64 + g.lane] = 0ull;
     LdsSpace::sync();
     if (valid) atomicOr(&T8[bk], 1ull << g.lane);
     LdsSpace::sync();
@@ -571,10 +572,11 @@ __device__ __forceinline__ Rank2 rank2_from_mates(const Grp<64> &g, bool valid1,
     const uint32_t first1 = valid1 ? (uint32_t)(__ffsll((long long)(from0 ? m10 : m11)) - 1) : lane;
     const uint32_t above1 = (uint32_t)__popcll(m11 & gt);
     const uint32_t lead1 = (valid1 && !from0 && first1 == lane) ? (uint32_t)__popcll(m11) : 0u;
-    const uint32_t incl1 = g.prefix_incl(lead1), tot1 = g.last(incl1);
-    const uint32_t incl0 = g.prefix_incl(lead0);
+    // both prefix sums in ONE scan: the sums stay below 2^16 (at most 128 elements), slot 1 rides in the upper half
+    const uint32_t incl = g.prefix_incl(lead0 | (lead1 << 16)), tot = g.last(incl);
+    const uint32_t incl0 = incl & 0xFFFFu, incl1 = incl >> 16, tot1 = tot >> 16;
     const uint32_t run1 = tot1 - incl1;                                   // buckets led from slot 1, higher lanes first
-    const uint32_t run0 = tot1 + (g.last(incl0) - incl0);                 // then those led from slot 0
+    const uint32_t run0 = tot1 + ((tot & 0xFFFFu) - incl0);               // then those led from slot 0
     const uint32_t st0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(first0 << 2), (int)run0);
     const uint32_t st1a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(first1 << 2), (int)run0);
     const uint32_t st1b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(first1 << 2), (int)run1);
