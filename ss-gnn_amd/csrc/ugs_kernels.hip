@@ -501,8 +501,8 @@ __device__ __forceinline__ uint32_t rank_in_registers(const Grp<64> &g, bool val
     LdsSpace::sync();
     const uint64_t mates = T8[bk];
     const uint32_t size = (uint32_t)__popcll(mates);
-    const uint32_t first = valid ? (uint32_t)(__ffsll((long long)mates) - 1) : (uint32_t)g.lane;
     const uint32_t above = (uint32_t)__popcll(mates & (~1ull << g.lane));
+    const uint32_t first = valid ? (uint32_t)(__ffsll((long long)mates) - 1) : (uint32_t)g.lane;
     const uint32_t lead = (valid && first == (uint32_t)g.lane) ? size : 0u;
     const uint32_t incl = g.prefix_incl(lead);
     const uint32_t run = g.last(incl) - incl;                              // ranks taken by buckets led from higher lanes
