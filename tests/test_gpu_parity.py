@@ -603,3 +603,27 @@ def test_presample_cache_assembles_batches_like_the_reference_trainer():
         want = [np.concatenate(nodes), np.concatenate(edges, axis=1), np.array(eptr), np.array(sptr), np.concatenate(esrc)]
         for a, b in zip(got, want):
             assert np.array_equal(a, b), order
+
+
+@pytest.mark.parametrize("tier", [None, "1", "2", "3"])
+def test_random_large_graphs_through_every_tier(tier, product, orc, monkeypatch):
+    """Mid-size random multigraphs (2 000 - 20 000 vertices, degree 6 - 300, columns in one or both directions, k up to 12):
+    candidate counts from a handful to more than a thousand, i.e. every variant of the order stages -- member masks of the
+    stages of <= 64 and <= 128 elements, the bucket-table finals with 2 ... 17 elements per lane, the materialised 257- and
+    541-element stages -- in every LDS tier (forced) and with the tier chosen by the host; all five outputs against the oracle."""
+    if tier is None:
+        monkeypatch.delenv("UGS_FORCE_TIER", raising=False)
+    else:
+        monkeypatch.setenv("UGS_FORCE_TIER", tier)
+    rng = random.Random(2024 + (int(tier) if tier else 0))
+    calls = []
+    for _ in range(8):
+        nv = rng.choice([2000, 5000, 20000])
+        deg = rng.choice([6, 20, 40, 80, 160, 300])
+        g = np.random.default_rng(rng.randrange(1 << 30))
+        ei = g.integers(0, nv, size=(2, nv * deg // 2), dtype=np.int64)
+        if rng.random() < 0.3:
+            ei = np.concatenate([ei, ei[::-1]], axis=1)
+        calls.append(dict(fn="sample_batch", edge_index=ei, ptr=np.array([0, nv], dtype=np.int64), m=rng.choice([64, 700, 2000]),
+                          k=rng.choice([3, 5, 8, 8, 10, 12]), mode=rng.choice(["sample", "graph", "global"]), seed=rng.choice([42, 0, 123456789])))
+    _same(calls, product, orc, f"large random graphs, tier {tier}")
