@@ -1567,13 +1567,16 @@ static hipError_t launch_lds(const UgsWalkArgs &a, int cus, int blocks_per_cu, h
 #ifndef UGS_BLOCKS_M
 #define UGS_BLOCKS_M 20
 #endif
+#ifndef UGS_BLOCKS_S
+#define UGS_BLOCKS_S 3      // 51.7 KB of LDS and 145 VGPRs per 256-thread block: three fit a CU (C4, 65 536 rows: walk 58 -> 47 us against two)
+#endif
 hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, int share_percent, hipStream_t s, UgsLaunchInfo *info) {
     if (cus <= 0) cus = 256;
     // share_percent < 100: the persistent grid takes only that share of the blocks a CU can hold, so that other kernels (the
     // collation, RCCL) find registers, LDS and wave slots on every CU while a walk is running (a full grid holds them to its end)
     auto part = [&](int blocks) { const int b = (int)((long long)blocks * (share_percent <= 0 || share_percent > 100 ? 100 : share_percent) / 100); return b < 1 ? 1 : b; };
     switch (tier) {
-    case UGS_TIER_S: return launch_lds<8, 64, 256>(a, cus, part(2), s, info, "ugs_walk_lds<8,64>");
+    case UGS_TIER_S: return launch_lds<8, 64, 256>(a, cus, part(UGS_BLOCKS_S), s, info, "ugs_walk_lds<8,64>");
     // one walk per wave: two walks per wave (GS 32) measured 26.4 ms vs 18.7 ms per 1M walks on C5 (two chunks per row)
     // resident one-wave blocks per CU: LDS is granted in 1280-byte granules (128 per CU) -- 7648 B = 6 granules -> 21 blocks, of
     // which the register budget (96 VGPRs: 5 waves per SIMD) admits 20; 19.5 KB = 16 granules -> 8; 38.9 KB = 31 granules -> 4
