@@ -627,3 +627,18 @@ def test_random_large_graphs_through_every_tier(tier, product, orc, monkeypatch)
         calls.append(dict(fn="sample_batch", edge_index=ei, ptr=np.array([0, nv], dtype=np.int64), m=rng.choice([64, 700, 2000]),
                           k=rng.choice([3, 5, 8, 8, 10, 12]), mode=rng.choice(["sample", "graph", "global"]), seed=rng.choice([42, 0, 123456789])))
     _same(calls, product, orc, f"large random graphs, tier {tier}")
+
+
+def test_whole_batch_index_on_a_batch_hashed_in_chunks(product, orc):
+    """A batch of more than 4 M columns is hashed in 8 MB chunks by helper threads (ugs_host.cpp: hash_array).  The same batch
+    again must give the same result (served through the index), and ONE changed column in the middle of a chunk, or a changed
+    last column, must be noticed -- a stale plan would reproduce the first result instead of the oracle's for the new batch."""
+    g = np.random.default_rng(404)
+    nv, cols = 60000, (1 << 22) + 12345
+    ei = g.integers(0, nv, size=(2, cols), dtype=np.int64)
+    ptr = np.array([0, nv], dtype=np.int64)
+    base = dict(fn="sample_batch", ptr=ptr, m=300, k=6, mode="sample", seed=42)
+    ei2 = ei.copy(); ei2[1, (1 << 21) + 777] = (ei2[1, (1 << 21) + 777] + 1) % nv
+    ei3 = ei.copy(); ei3[0, cols - 1] = (ei3[0, cols - 1] + 1) % nv
+    calls = [dict(base, edge_index=ei), dict(base, edge_index=ei), dict(base, edge_index=ei2), dict(base, edge_index=ei3), dict(base, edge_index=ei)]
+    _same(calls, product, orc, "chunk-hashed batch")
