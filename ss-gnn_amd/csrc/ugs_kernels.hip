@@ -1353,6 +1353,26 @@ __global__ __launch_bounds__(kScanBlock) void ugs_scan_final(const uint32_t *cou
     if (rows - 1 >= base && rows - 1 < base + kScanPer) edge_ptr[rows] = ex;   // owner of the last row writes the total
 }
 
+// Two launches instead of three for up to 4096 tiles (8M rows): every block of the final pass sums the tile totals in front of
+// its own tile itself (at most 16 loads per thread and one block reduction; no flags, no waiting)
+__global__ __launch_bounds__(kScanBlock) void ugs_scan_final_sum(const uint32_t *counts, int64_t rows, const int64_t *tile_sums,
+                                                                 int64_t *edge_ptr) {
+    __shared__ int64_t sh[kScanBlock / 64];
+    int64_t before = 0, front;
+    for (int64_t i = threadIdx.x; i < (int64_t)blockIdx.x; i += kScanBlock) before += tile_sums[i];
+    block_excl_scan(before, &front, sh);
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanPer;
+    uint32_t v[kScanPer];
+    int64_t s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) { v[j] = (base + j < rows) ? (counts[base + j] & ~UGS_COUNT_STAGED) : 0u; s += v[j]; }
+    int64_t tot;
+    int64_t ex = block_excl_scan(s, &tot, sh) + front;
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) { if (base + j < rows) edge_ptr[base + j] = ex; ex += v[j]; }
+    if (rows - 1 >= base && rows - 1 < base + kScanPer) edge_ptr[rows] = ex;   // owner of the last row writes the total
+}
+
 // single-block variant for small row counts (one launch instead of three): 1024 threads, 8192 rows per round
 constexpr int kScanWide = 1024;
 __global__ __launch_bounds__(kScanWide) void ugs_scan_small(const uint32_t *counts, int64_t rows, int64_t *edge_ptr) {
@@ -1621,6 +1641,10 @@ hipError_t ugs_launch_scan(const uint32_t *counts, int64_t rows, int64_t *edge_p
     }
     const int64_t nb = (rows + kScanTile - 1) / kScanTile;
     hipLaunchKernelGGL(ugs_scan_partials, dim3((unsigned)nb), dim3(kScanBlock), 0, s, counts, rows, block_tmp);
+    if (nb <= 4096) {
+        hipLaunchKernelGGL(ugs_scan_final_sum, dim3((unsigned)nb), dim3(kScanBlock), 0, s, counts, rows, (const int64_t *)block_tmp, edge_ptr);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(ugs_scan_block_sums, dim3(1), dim3(kScanBlock), 0, s, block_tmp, nb);
     hipLaunchKernelGGL(ugs_scan_final, dim3((unsigned)nb), dim3(kScanBlock), 0, s, counts, rows, (const int64_t *)block_tmp, edge_ptr);
     return hipGetLastError();
