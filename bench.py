@@ -235,11 +235,13 @@ class Job:
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(self.side)
-            res = self.collator.collate((self.nodes[b], self.eidx[b], self.eptr[b], self.esrc[b]))
+            self.collator.pack((self.nodes[b], self.eidx[b], self.eptr[b], self.esrc[b]))
+            self.ev_collated[b].record(self.side)                # the buffer set is free as soon as it has been PACKED: the exchange
+            self.collator.exchange()                             # and the unpack may lag behind the sampling without stalling it
+            res = self.collator.unpack()
             if timed:
                 e1.record(self.side)
                 self.cev.append((e0, e1))
-            self.ev_collated[b].record(self.side)
         self.collated_once[b] = True
         return res
 
