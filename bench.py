@@ -49,7 +49,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-reference", action="store_true", help="skip timing the reference C++ itself (oracle/_ref) on the headline workload; its preprocessing takes about half a minute on C5")
-    ap.add_argument("--walk-share", type=int, default=80, help="percent of each CU the walk kernels occupy while a collation runs beside them (N > 1)")
+    ap.add_argument("--walk-share", type=int, default=80, help="DESTINATION rank: percent of each CU its walk kernels occupy, so that the unpack of the "
+                    "previous batch (and RCCL's receive kernels) find room beside them (N > 1)")
+    ap.add_argument("--walk-share-others", type=int, default=100, help="the other ranks only pack and send: their walk kernels keep the whole CU")
+    ap.add_argument("--dst-rows", default="auto", help="N > 1: the destination's share of the rows.  'auto' (default): measured -- two short local "
+                    "calibration rounds in the warm-up (each rank's own work per step, no exchange), one all-gather each, then rows in proportion to "
+                    "rows per millisecond; 'equal': the equal split; a number w: weight of the destination against 1.0 for every other rank")
     ap.add_argument("--force-collate", action="store_true", help="run the multi-GPU collation path even with one rank (rehearsal)")
     ap.add_argument("--rehearse", action="store_true", help="N ranks on ONE GPU over gloo (every rank uses cuda:0): exercises the multi-rank control flow "
                     "of this script where only one GPU is at hand; the numbers mean nothing")
@@ -187,10 +192,11 @@ def split_algorithmic_bytes(nodes, edge_ptr, k, deg):
 class Job:
     """One sharded sampling job on this rank: buffers, the step function and (N > 1) the collation on a side stream."""
 
-    def __init__(self, torch, dist, ud, plan, args, G, m_total, k, rank, world, dev, node_bound, n_cols, use_collate):
+    def __init__(self, torch, dist, ud, plan, args, G, m_total, k, rank, world, dev, node_bound, n_cols, use_collate, weights=None):
         self.torch, self.plan, self.args, self.k, self.m_total = torch, plan, args, k, m_total
         self.total_rows = G * m_total
-        self.row_begin, self.row_count = ud.shard_range(self.total_rows, rank, world)
+        self.row_off = ud.shard_offsets(self.total_rows, world, weights)      # the same list on every rank
+        self.row_begin, self.row_count = self.row_off[rank], self.row_off[rank + 1] - self.row_off[rank]
         self.use_collate = use_collate
         nsets = 2 if use_collate else 1       # double buffering: step s samples into set s%2 while set (s-1)%2 is collated
         self.nsets = nsets
@@ -208,7 +214,8 @@ class Job:
         self.main = torch.cuda.current_stream()
         if use_collate:
             self.side = torch.cuda.Stream(device=dev)
-            self.collator = ud.Collator(self.total_rows, k, args.mode, node_bound, max(node_bound, m_total * k), n_cols, self.cap, dev, dst=0)
+            self.collator = ud.Collator(self.total_rows, k, args.mode, node_bound, max(node_bound, m_total * k), n_cols, self.cap, dev, dst=0,
+                                        row_off=self.row_off)
             self.ev_sampled = [torch.cuda.Event() for _ in range(nsets)]
             self.ev_collated = [torch.cuda.Event() for _ in range(nsets)]
             self.collated_once = [False] * nsets
@@ -227,8 +234,9 @@ class Job:
         if self.use_collate:
             self.ev_sampled[b].record(self.main)
 
-    def collate_step(self, i, timed):
-        """the one exchange step: collate batch i on rank 0 (side stream, overlaps the sampling of batch i+1)"""
+    def collate_step(self, i, timed, exchange=True):
+        """the one exchange step: collate batch i on rank 0 (side stream, overlaps the sampling of batch i+1).  exchange=False
+        (calibration): this rank's own part only -- pack, and on the destination the unpack of the messages already in its inbox"""
         torch, b = self.torch, i % self.nsets
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.ev_sampled[b])
@@ -237,7 +245,8 @@ class Job:
                 e0.record(self.side)
             self.collator.pack((self.nodes[b], self.eidx[b], self.eptr[b], self.esrc[b]))
             self.ev_collated[b].record(self.side)                # the buffer set is free as soon as it has been PACKED: the exchange
-            self.collator.exchange()                             # and the unpack may lag behind the sampling without stalling it
+            if exchange:
+                self.collator.exchange()                         # and the unpack may lag behind the sampling without stalling it
             res = self.collator.unpack()
             if timed:
                 e1.record(self.side)
@@ -245,17 +254,28 @@ class Job:
         self.collated_once[b] = True
         return res
 
-    def run_steps(self, first, count, timed=False):
+    def run_steps(self, first, count, timed=False, exchange=True):
         """`count` complete steps: every batch sampled AND (multi-GPU) collated inside the call"""
         res = None
         for i in range(first, first + count):
             self.sample(i)
             if self.use_collate and i > first:
-                self.collate_step(i - 1, timed)
+                self.collate_step(i - 1, timed, exchange)
         if self.use_collate and count > 0:
-            res = self.collate_step(first + count - 1, timed)
+            res = self.collate_step(first + count - 1, timed, exchange)
             self.side.synchronize()
         return res
+
+    def local_ms_per_step(self, steps=8):
+        """calibration: this rank's OWN work per step in steady state (sampling; pack; on the destination the unpack of a whole
+        batch beside the next step's sampling) with no exchange, so that no rank's time contains another rank's"""
+        torch = self.torch
+        self.run_steps(2000, 2, exchange=False)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        self.run_steps(2002, steps, exchange=False)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / steps * 1e3
 
 
 def timed_run(torch, dist, job, steps, warmup, world, dev):
@@ -340,23 +360,62 @@ def main():
     node_bound = int(ptr[-1])
     use_collate = world > 1 or args.force_collate
     m_total = m * world if args.scaling == "weak" else m
+    my_share = 100
     if use_collate:
-        plan.set_walk_share(args.walk_share)              # room on every CU for the collation + RCCL kernels of the previous batch
-    job = Job(torch, dist, ud, plan, args, G, m_total, k, rank, world, dev, node_bound, ei.shape[1], use_collate)
+        # the destination's walk kernels leave room on every CU for the unpack + RCCL kernels of the previous batch; the other ranks
+        # only pack and send (copy kernels of a few microseconds) and keep the whole CU
+        my_share = args.walk_share if rank == 0 else args.walk_share_others
+        plan.set_walk_share(my_share)
+    plan.set_timing(False)
+    # ---- the split of the rows over the ranks (N > 1): equal, given, or measured in the warm-up ---------------------------------
+    weights, calibration = None, None
+    if world > 1 and args.dst_rows != "equal":
+        if args.dst_rows != "auto":
+            weights = [float(args.dst_rows)] + [1.0] * (world - 1)
+        else:
+            # Rank 0 also unpacks the whole batch, so with equal shards it is the critical path of every step.  Each round: one real
+            # step (fills the destination's inbox), then every rank times its own steady-state work without the exchange; one
+            # all-gather of (rows, ms); next weights = rows per millisecond.  A rank's time is rows * s + f with a fixed part f
+            # (the destination's unpack), so the proportional update is repeated once: it contracts towards equal times.
+            calibration = []
+            for _ in range(2):
+                cj = Job(torch, dist, ud, plan, args, G, m_total, k, rank, world, dev, node_bound, ei.shape[1], True, weights)
+                cj.run_steps(0, 1)
+                torch.cuda.synchronize()
+                mine = torch.tensor([float(cj.row_count), cj.local_ms_per_step()], dtype=torch.float64, device=dev)
+                every = torch.empty((world, 2), dtype=torch.float64, device=dev)
+                dist.all_gather_into_tensor(every, mine.reshape(1, 2))
+                every = every.cpu().tolist()
+                calibration.append({"rows": [int(r_) for r_, _ in every], "local_ms_per_step": [round(t_, 4) for _, t_ in every]})
+                weights = [max(r_, 1.0) / max(t_, 1e-6) for r_, t_ in every]
+                del cj
+    job = Job(torch, dist, ud, plan, args, G, m_total, k, rank, world, dev, node_bound, ei.shape[1], use_collate, weights)
     total_rows, row_begin, row_count = job.total_rows, job.row_begin, job.row_count
 
-    plan.set_timing(False)
     job.run_steps(0, 1)                                   # first touch of every buffer outside the event-timed region
     torch.cuda.synchronize()
     plan.set_timing(True)
     elapsed, collate_ms = timed_run(torch, dist, job, args.steps, args.warmup, world, dev)
     timing = plan.get_timing()
     plan.set_timing(False)
+    per_rank = None
+    if use_collate:                                       # every rank's rows and kernel times, for rank 0's line (a collective: before the ranks part)
+        tm = lambda key: timing[key][0] / max(timing[key][1], 1)     # noqa: E731
+        mine = torch.tensor([float(row_count), tm("walk"), tm("scan"), tm("fill"), float(collate_ms or 0.0), float(my_share)], dtype=torch.float64, device=dev)
+        every = torch.empty((world, 6), dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_gather_into_tensor(every, mine.reshape(1, 6))
+        else:
+            every.copy_(mine.reshape(1, 6))
+        per_rank = [{"rank": r_, "rows": int(v[0]), "walk_ms": round(v[1], 4), "scan_ms": round(v[2], 4), "fill_ms": round(v[3], 4),
+                     "collate_ms": round(v[4], 4), "walk_share": int(v[5])} for r_, v in enumerate(every.cpu().tolist())]
+        if job.collator.overflowed():                     # lazy capacity check of the collation (one read-back, after the timed region)
+            raise SystemExit("a step's edge total exceeded the collation capacity: result invalid")
 
     extras = {}
     if world > 1 and args.scaling == "strong" and not args.no_extras:
         # the other scaling mode, short: every rank adds a whole batch (N*B rows per step collated on rank 0)
-        wjob = Job(torch, dist, ud, plan, args, G, m * world, k, rank, world, dev, node_bound, ei.shape[1], True)
+        wjob = Job(torch, dist, ud, plan, args, G, m * world, k, rank, world, dev, node_bound, ei.shape[1], True, weights)
         wsteps = max(3, args.steps // 2)
         wel, wcms = timed_run(torch, dist, wjob, wsteps, 2, world, dev)
         extras["weak_scaling"] = {"value": round(wjob.total_rows * wsteps / wel, 1), "ms_per_step": round(wel / wsteps * 1e3, 4), "steps": wsteps,
@@ -485,8 +544,10 @@ def main():
            "config": {"workload": args.workload, "graphs": G, "columns": int(ei.shape[1]), "k": k, "rows_per_gpu": row_count,
                       "global_rows": total_rows, "mode": args.mode, "sharding": f"rows{world}" if world > 1 else "none",
                       "collate": "gather to rank 0 over RCCL every step (fixed-size narrowed messages, device-side offsets, no host round trip), "
-                                 f"overlapped with the next step's sampling (walk kernels on {args.walk_share}% of each CU)" if use_collate else "none (single GPU)"},
+                                 f"overlapped with the next step's sampling (walk kernels on {args.walk_share}% of each CU on the destination, "
+                                 f"{args.walk_share_others}% elsewhere); rows split {args.dst_rows}" if use_collate else "none (single GPU)"},
            "collate_ms_per_step": round(collate_ms, 4) if collate_ms is not None else None,
+           "per_rank": per_rank, "split_calibration": calibration,
            "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_port": cpu_port if cpu_baseline else None,
            "cpu_baseline_all_cores": cpu_all, "parity_checked_rows": parity_rows,
            "parity_checked_tensors": ["nodes", "edge_ptr", "edge_index", "edge_src"] if parity_rows else []}
@@ -579,20 +640,56 @@ def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
         evs.append((a, b))
     torch.cuda.synchronize()
     dt_wall = (time.perf_counter() - t) / reps
+    # roofline block of this workload's dominant kernel: per-kernel HIP events of the library on the launch stream (a second loop,
+    # so that the events do not sit inside the step times above), SURVEY.md 8(d) bytes measured on the step's own output
+    plan.set_timing(True)
+    for i in range(reps):
+        plan.walk(m, "sample", 42 + i, 0, rows, out=(nodes, eptr), sync=False)
+        plan.fill(m, nodes, eptr, None, "sample", 0, out=(eidx, esrc))
+    torch.cuda.synchronize()
+    tk = plan.get_timing()
+    plan.set_timing(False)
+    kms = {key: tk[key][0] / max(tk[key][1], 1) for key in ("walk", "scan", "fill")}
+    launch = plan.last_launch()
+    plan.walk(m, "sample", 42, 0, rows, out=(nodes, eptr), sync=True)
+    wb, fb = split_algorithmic_bytes(nodes.cpu().numpy(), eptr.cpu().numpy(), k, csr_degrees(ei, int(ptr[-1])))
+    ach = wb * rows / (kms["walk"] * 1e-3) / 1e9 if kms["walk"] > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": launch["kernel"], "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
+                "traffic": None, "algorithmic_bytes_per_unit": round(wb, 1), "units_per_launch": rows, "kernel_ms": round(kms["walk"], 4),
+                "grid": launch["grid"], "block": launch["block"], "lds_bytes_per_block": launch["lds_bytes"],
+                "path": {"algorithmic_bytes_per_unit": round(wb + fb, 1), "scan_ms": round(kms["scan"], 4), "fill_kernel_ms": round(kms["fill"], 4),
+                         "gpu_ms_per_step": round(sum(kms.values()), 4)},
+                "note": "graphs of this size are L2-resident: the kernel is latency- and launch-bound, the HBM fraction is reported for completeness"}
     per = sorted(a.elapsed_time(b) for a, b in evs)
     dt_dev = per[len(per) // 2] * 1e-3                                     # median repetition (a single stalled one does not move it)
     # the same step captured once as a HIP graph and replayed (Plan.graph_step)
-    dt_graph = None
+    # EVERY replay is timed twice -- HIP events around it on the stream (device side) and the host clock around the launch call --
+    # and the median, the maximum and the index of the maximum are reported: a bare mean over the loop hid a single stalled
+    # replay (round 2: 1.77 ms "per replay" in the driver's run against 0.09 ms in every other run).
+    dt_graph, graph_stats = None, None
     try:
         step = plan.graph_step(m, "sample", 0, rows, edge_capacity=cap)
         for i in range(5):
             step.launch(42 + i)
         torch.cuda.synchronize()
+        gev, host_us = [], []
         t = time.perf_counter()
         for i in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            th = time.perf_counter()
             step.launch(42 + i)
+            host_us.append((time.perf_counter() - th) * 1e6)
+            b.record()
+            gev.append((a, b))
         torch.cuda.synchronize()
-        dt_graph = (time.perf_counter() - t) / reps
+        wall = (time.perf_counter() - t) / reps
+        dev_ms = [a.elapsed_time(b) for a, b in gev]
+        srt = sorted(dev_ms)
+        dt_graph = srt[len(srt) // 2] * 1e-3
+        graph_stats = {"median_ms": round(srt[len(srt) // 2], 4), "max_ms": round(srt[-1], 4), "index_of_max": int(dev_ms.index(srt[-1])),
+                       "wall_mean_ms": round(wall * 1e3, 4), "host_launch_call_us_median": round(sorted(host_us)[len(host_us) // 2], 1),
+                       "host_launch_call_us_max": round(max(host_us), 1), "index_of_host_max": int(host_us.index(max(host_us))), "replays": reps}
         step.close()
     except Exception as e:   # noqa: BLE001
         print(f"[bench] graph step on {name} failed: {e}", file=sys.stderr)
@@ -624,9 +721,10 @@ def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
     res = {"rows": rows, "k": k, "device_resident_subgraphs_per_s": round(rows / dt_dev, 1), "device_resident_ms": round(dt_dev * 1e3, 4),
            "device_resident_ms_max_rep": round(per[-1], 4), "device_resident_ms_wall_mean": round(dt_wall * 1e3, 4),
            "hip_graph_replay_subgraphs_per_s": round(rows / dt_graph, 1) if dt_graph else None,
-           "hip_graph_replay_ms": round(dt_graph * 1e3, 4) if dt_graph else None,
+           "hip_graph_replay_ms": round(dt_graph * 1e3, 4) if dt_graph else None, "hip_graph_replay": graph_stats,
            "drop_in_call_subgraphs_per_s": round(rows / dt_host, 1), "drop_in_call_ms": round(dt_host * 1e3, 4),
-           "drop_in_call_shuffled_batch_ms": round(dt_shuf * 1e3, 4), "drop_in_call_device_out_ms": round(dt_devout * 1e3, 4)}
+           "drop_in_call_shuffled_batch_ms": round(dt_shuf * 1e3, 4), "drop_in_call_device_out_ms": round(dt_devout * 1e3, 4),
+           "roofline": roofline}
     try:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle

@@ -167,12 +167,17 @@ int ugs_plan_last_launch(const ugs_plan *plan, char *name_buf, int name_buf_len,
  *      rows_cap / edge_cap are the job's fixed capacities (>= every rank's rows / edge entries), so message size does not depend
  *      on a step's outcome and no host round trip is needed per step.
  *      ugs_collate_unpack turns `world` messages (contiguous, d_msgs[world][msg_bytes]) into the batch's int64 tensors on the
- *      device: offsets are taken from the headers ON the device, entries at positions >= ld are not written. */
+ *      device: offsets are taken from the headers ON the device, entries at positions >= ld are not written.  A message whose
+ *      edge total exceeds edge_cap was truncated by its sender: the batch is then INVALID; d_max_total (one device word, kept
+ *      by the caller across steps) receives the largest total seen so that the caller can find out without a per-step host
+ *      round trip (total > edge_cap). */
 int ugs_collate_layout(int k, int node_bytes, int eidx_bytes, int esrc_bytes, int64_t rows_cap, int64_t edge_cap,
                        int64_t *section_off4, int64_t *msg_bytes);
 int ugs_collate_unpack(const void *d_msgs, int world, const int64_t *row_off /* host, world+1 */, int k, int node_bytes,
                        int eidx_bytes, int esrc_bytes, int64_t rows_cap, int64_t edge_cap, int64_t *d_nodes,
-                       int64_t *d_edge_index, int64_t ld, int64_t *d_edge_ptr, int64_t *d_edge_src, void *stream);
+                       int64_t *d_edge_index, int64_t ld, int64_t *d_edge_ptr, int64_t *d_edge_src,
+                       int64_t *d_max_total /* optional: max(*d_max_total, every message's edge total), for a lazy capacity check */,
+                       void *stream);
 
 /* ---- epsilon_uniform_sampler.sample_batch(edge_index, ptr, m_per_graph, k, mode, seed, epsilon): replaces the reference's
  *      src/samplers/epsilon_uniform_sampler/src/epsilon_uniform_sampler.cpp:122-377.

@@ -9,7 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "libugs_mi355.so")
 SRCS = [os.path.join(HERE, "ugs_kernels.hip"), os.path.join(HERE, "ugs_eps.hip"), os.path.join(HERE, "ugs_preproc.hip"), os.path.join(HERE, "ugs_collate.hip"), os.path.join(HERE, "ugs_host.cpp"),
         os.path.join(HERE, "ugs_apx.cpp"), os.path.join(HERE, "ugs_apx_gpu.hip")]
-DEPS = SRCS + [os.path.join(HERE, "ugs_device.h"), os.path.join(HERE, "ugs_apx_common.h"), os.path.join(HERE, "..", "..", "include", "ugs_mi355.h")]
+HDRS = [os.path.join(HERE, "ugs_device.h"), os.path.join(HERE, "ugs_apx_common.h"), os.path.join(HERE, "..", "..", "include", "ugs_mi355.h")]
+DEPS = SRCS + HDRS
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
@@ -20,6 +21,8 @@ def build(force=False, verbose=False):
 
     def compile_one(src):
         obj = os.path.splitext(src)[0] + ".o"
+        if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src, __file__] + HDRS):
+            return obj                                       # object is newer than its source, the headers and this recipe
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
                "-x", "hip", "-c", src, "-o", obj]
         if src.endswith("ugs_kernels.hip"):

@@ -19,6 +19,7 @@ struct CollateArgs {
     int64_t row_off[UGS_COLLATE_MAX_WORLD + 1];         // first batch row of every rank (host-known: the row ranges are fixed)
     int64_t *nodes, *edge_index, *edge_ptr, *edge_src;
     int64_t ld;
+    long long *max_total;                               // optional: largest per-rank edge total seen (the caller's capacity check)
 };
 
 __device__ __forceinline__ int64_t widen(const unsigned char *p, int64_t i, int bytes, bool sign) {
@@ -50,6 +51,8 @@ __global__ __launch_bounds__(256) void ugs_collate_rows(CollateArgs a) {
     if (i < rows * a.k) a.nodes[a.row_off[r] * a.k + i] = widen(m + a.off_nodes, i, a.node_b, true);
     if (i < rows) a.edge_ptr[a.row_off[r] + i] = off + (int64_t)reinterpret_cast<const uint32_t *>(m + a.off_eptr)[i];
     if (r == a.world - 1 && i == 0) a.edge_ptr[a.row_off[a.world]] = off + reinterpret_cast<const int64_t *>(m)[1];
+    // a total above edge_cap means the sender truncated its message: the caller compares this word with its capacity, lazily
+    if (a.max_total && i == 0) atomicMax(a.max_total, (long long)reinterpret_cast<const int64_t *>(m)[1]);
 }
 
 // edge entries: a block takes 1024 consecutive entries of one rank, four per thread at a stride of 256 (coalesced reads of the
@@ -81,7 +84,8 @@ __global__ __launch_bounds__(256) void ugs_collate_edges(CollateArgs a) {
 
 hipError_t ugs_launch_collate_unpack(const void *d_msgs, int world, int64_t msg_bytes, const int64_t *row_off, int k, int node_b, int eidx_b,
                                      int esrc_b, int64_t rows_cap, int64_t edge_cap, const int64_t *section_off4, int64_t *d_nodes,
-                                     int64_t *d_edge_index, int64_t ld, int64_t *d_edge_ptr, int64_t *d_edge_src, hipStream_t s) {
+                                     int64_t *d_edge_index, int64_t ld, int64_t *d_edge_ptr, int64_t *d_edge_src, int64_t *d_max_total,
+                                     hipStream_t s) {
     CollateArgs a{};
     a.msgs = static_cast<const unsigned char *>(d_msgs);
     a.msg_bytes = msg_bytes;
@@ -90,6 +94,7 @@ hipError_t ugs_launch_collate_unpack(const void *d_msgs, int world, int64_t msg_
     a.off_nodes = section_off4[0]; a.off_eptr = section_off4[1]; a.off_eidx = section_off4[2]; a.off_esrc = section_off4[3];
     for (int r = 0; r <= world; ++r) a.row_off[r] = row_off[r];
     a.nodes = d_nodes; a.edge_index = d_edge_index; a.edge_ptr = d_edge_ptr; a.edge_src = d_edge_src; a.ld = ld;
+    a.max_total = reinterpret_cast<long long *>(d_max_total);
     const unsigned gx_rows = (unsigned)(((rows_cap > 0 ? rows_cap : 1) * (int64_t)k + 255) / 256);
     hipLaunchKernelGGL(ugs_collate_rows, dim3(gx_rows, (unsigned)world), dim3(256), 0, s, a);
     if (edge_cap > 0) {

@@ -136,7 +136,8 @@ hipError_t ugs_launch_build_prow(const UgsPlanDev &plan, int64_t num_vertices, i
 #define UGS_COLLATE_MAX_WORLD 64
 hipError_t ugs_launch_collate_unpack(const void *d_msgs, int world, int64_t msg_bytes, const int64_t *row_off, int k, int node_b, int eidx_b,
                                      int esrc_b, int64_t rows_cap, int64_t edge_cap, const int64_t *section_off4, int64_t *d_nodes,
-                                     int64_t *d_edge_index, int64_t ld, int64_t *d_edge_ptr, int64_t *d_edge_src, hipStream_t s);
+                                     int64_t *d_edge_index, int64_t ld, int64_t *d_edge_ptr, int64_t *d_edge_src, int64_t *d_max_total,
+                                     hipStream_t s);
 hipError_t ugs_launch_scan(const uint32_t *counts, int64_t rows, int64_t *edge_ptr, int64_t *block_tmp, hipStream_t s);
 hipError_t ugs_launch_fill(const UgsFillArgs &a, int wide, int device_cus, hipStream_t s, UgsLaunchInfo *info);
 int64_t ugs_scan_tmp_words(int64_t rows);

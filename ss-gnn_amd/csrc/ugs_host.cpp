@@ -1411,7 +1411,7 @@ int ugs_collate_layout(int k, int node_bytes, int eidx_bytes, int esrc_bytes, in
 
 int ugs_collate_unpack(const void *d_msgs, int world, const int64_t *row_off, int k, int node_bytes, int eidx_bytes, int esrc_bytes,
                        int64_t rows_cap, int64_t edge_cap, int64_t *d_nodes, int64_t *d_edge_index, int64_t ld, int64_t *d_edge_ptr,
-                       int64_t *d_edge_src, void *stream) {
+                       int64_t *d_edge_src, int64_t *d_max_total, void *stream) {
     if (!d_msgs || !row_off || world < 1 || world > UGS_COLLATE_MAX_WORLD) return fail(UGS_E_BAD_ARG, "collate: 1 <= world <= 64 messages expected");
     if (!d_nodes || !d_edge_ptr || (edge_cap > 0 && (!d_edge_index || !d_edge_src))) return fail(UGS_E_BAD_ARG, "null output pointer");
     int64_t so[4], mb = 0;
@@ -1419,7 +1419,7 @@ int ugs_collate_unpack(const void *d_msgs, int world, const int64_t *row_off, in
     for (int r = 0; r < world; ++r)
         if (row_off[r + 1] < row_off[r] || row_off[r + 1] - row_off[r] > rows_cap) return fail(UGS_E_BAD_ARG, "collate: a rank's row range exceeds rows_cap");
     HIP_TRY(ugs_launch_collate_unpack(d_msgs, world, mb, row_off, k, node_bytes, eidx_bytes, esrc_bytes, rows_cap, edge_cap, so, d_nodes,
-                                      d_edge_index, ld, d_edge_ptr, d_edge_src, static_cast<hipStream_t>(stream)));
+                                      d_edge_index, ld, d_edge_ptr, d_edge_src, d_max_total, static_cast<hipStream_t>(stream)));
     return UGS_OK;
 }
 

@@ -51,7 +51,7 @@ def _load():
         "ugs_plan_graph_launch": [vp, C.c_int, vp],
         "ugs_plan_graph_destroy": [vp],
         "ugs_collate_layout": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, i64p, i64p],
-        "ugs_collate_unpack": [vp, C.c_int, i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, vp, C.c_int64, vp, vp, vp],
+        "ugs_collate_unpack": [vp, C.c_int, i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, vp, C.c_int64, vp, vp, vp, vp],
         "ugs_plan_set_walk_share": [vp, C.c_int],
         "ugs_plan_set_timing": [vp, C.c_int],
         "ugs_plan_get_timing": [vp, C.POINTER(C.c_double), i64p],

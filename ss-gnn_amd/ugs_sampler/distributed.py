@@ -23,11 +23,39 @@ import torch
 import torch.distributed as dist
 
 
-def shard_range(total_rows, rank, world):
-    """Contiguous row range of `rank`: sizes differ by at most one row."""
-    base, rem = divmod(int(total_rows), int(world))
-    begin = rank * base + min(rank, rem)
-    return begin, base + (1 if rank < rem else 0)
+def shard_offsets(total_rows, world, weights=None):
+    """First row of every rank's contiguous range, plus the total: world + 1 non-decreasing offsets.
+
+    weights=None: the equal split (sizes differ by at most one row).  Otherwise `weights[r]` is the share of rank r (any
+    non-negative numbers, e.g. rows per millisecond measured in a warm-up): rank r gets total * w[r] / sum(w) rows, rounded so
+    that the ranges cover [0, total) exactly (largest remainders first, ties to the lower rank) -- a deterministic function
+    of its arguments, so every rank computes the same split from the same all-gathered weights.  Any split is legal: row i
+    depends only on (graph, seed, i) (reference src/sampler.cpp:158-161)."""
+    total, world = int(total_rows), int(world)
+    if weights is None:
+        base, rem = divmod(total, world)
+        sizes = [base + (1 if r < rem else 0) for r in range(world)]
+    else:
+        w = [float(x) for x in weights]
+        if len(w) != world or any(not (x >= 0.0) or x == float("inf") for x in w) or not sum(w) > 0.0:
+            raise ValueError("shard weights: one finite non-negative number per rank, not all zero")
+        tot_w = sum(w)
+        exact = [total * x / tot_w for x in w]
+        sizes = [int(e) for e in exact]
+        left = total - sum(sizes)
+        order = sorted(range(world), key=lambda r: (-(exact[r] - sizes[r]), r))
+        for r in order[:left]:
+            sizes[r] += 1
+    off = [0]
+    for c in sizes:
+        off.append(off[-1] + c)
+    return off
+
+
+def shard_range(total_rows, rank, world, weights=None):
+    """Contiguous row range (begin, count) of `rank` under shard_offsets(total_rows, world, weights)."""
+    off = shard_offsets(total_rows, world, weights)
+    return off[rank], off[rank + 1] - off[rank]
 
 
 def _wire_dtypes(k, mode, node_id_bound, edge_id_bound, col_bound):
@@ -53,17 +81,26 @@ def _layout(k, nb, eb, sb, rows_cap, edge_cap):
 class Collator:
     """Collates the ranks' results of one sharded job, step after step, without host synchronisation.
 
-    total_rows        G * m_per_graph of the job; rank r owns shard_range(total_rows, r, world)
-    edge_cap          capacity in edge entries of ONE rank's result (the same number on every rank; take it from a probe step)
+    total_rows        G * m_per_graph of the job; rank r owns rows [row_off[r], row_off[r+1])
+    row_off           world + 1 offsets (shard_offsets(total_rows, world, weights)); None = the equal split.  Uneven splits are
+                      how the destination rank -- which also unpacks the whole batch -- is given fewer rows to sample
+    edge_cap          capacity in edge entries of ONE rank's result: an UPPER BOUND, the same number on every rank (rows_cap *
+                      2k(k-1) always holds; a probe step plus a margin is the practical choice -- then poll overflowed())
     node_id_bound / edge_id_bound / col_bound   exclusive bounds of the values in nodes / edge_index / edge_src (wire widths)
     dst / all_ranks   the batch is produced on rank `dst` only (gather), or on every rank (all-gather)
 
     collate(local) takes this rank's (nodes [rows,k], edge_index [2,>=t], edge_ptr [rows+1], edge_src [>=t]) int64 tensors and
     returns, on the destination(s), (nodes [B,k], edge_index [2,world*edge_cap], edge_ptr [B+1], edge_src [world*edge_cap]) --
-    buffers owned by the collator, overwritten by the next call -- and None elsewhere."""
+    buffers owned by the collator, overwritten by the next call -- and None elsewhere.
+
+    Overflow: a step whose edge total on some rank exceeds edge_cap cannot be represented (the message is fixed-size); the
+    entries beyond the capacity are dropped and the step's result is INVALID.  This is detected on the device without a host
+    round trip: `max_total` (a one-word device tensor) holds the largest per-rank total seen -- by pack() on every rank for its
+    own totals, by unpack() on the destination for all ranks' -- and overflowed() / check() read it back (one host
+    synchronisation: call them lazily, e.g. once per epoch, or before trusting a batch)."""
 
     def __init__(self, total_rows, k, mode, node_id_bound, edge_id_bound, col_bound, edge_cap, device, group=None, dst=0,
-                 all_ranks=False, world=None, rank=None):
+                 all_ranks=False, world=None, rank=None, row_off=None):
         self.group, self.dst, self.all_ranks = group, dst, all_ranks
         if world is None:
             self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
@@ -73,24 +110,31 @@ class Collator:
             raise RuntimeError("Collator: at most 64 ranks")
         self.k, self.total_rows, self.edge_cap = int(k), int(total_rows), int(edge_cap)
         self.dev = torch.device(device)
-        spans = [shard_range(total_rows, r, self.world) for r in range(self.world)]
-        self.row_off = [s[0] for s in spans] + [self.total_rows]
-        self.rows = spans[self.rank][1]
-        self.rows_cap = max(s[1] for s in spans)
+        self.row_off = shard_offsets(total_rows, self.world) if row_off is None else [int(x) for x in row_off]
+        if len(self.row_off) != self.world + 1 or self.row_off[0] != 0 or self.row_off[-1] != self.total_rows or \
+                any(self.row_off[r + 1] < self.row_off[r] for r in range(self.world)):
+            raise RuntimeError("Collator: row_off must be world + 1 non-decreasing offsets from 0 to total_rows")
+        self.rows = self.row_off[self.rank + 1] - self.row_off[self.rank]
+        self.rows_cap = max(self.row_off[r + 1] - self.row_off[r] for r in range(self.world))
         self.nd, self.ed, self.sd = _wire_dtypes(k, mode, node_id_bound, edge_id_bound, col_bound)
         self.nb, self.eb, self.sb = (torch.empty((), dtype=d).element_size() for d in (self.nd, self.ed, self.sd))
         self.sec, self.nbytes = _layout(self.k, self.nb, self.eb, self.sb, self.rows_cap, self.edge_cap)
         self.msg = torch.zeros(self.nbytes, dtype=torch.uint8, device=self.dev)
         self._views = self._sections(self.msg)
         self._views[0][0] = self.rows                          # header: this rank's row count never changes
+        self.max_total = torch.zeros(1, dtype=torch.int64, device=self.dev)   # largest per-rank edge total seen (device; see overflowed())
         self.is_dst = all_ranks or self.rank == dst
         if self.is_dst:
             self.inbox = torch.zeros((self.world, self.nbytes), dtype=torch.uint8, device=self.dev)
             cap = self.world * self.edge_cap
             self.out_nodes = torch.empty((self.total_rows, self.k), dtype=torch.int64, device=self.dev)
             self.out_eptr = torch.empty((self.total_rows + 1,), dtype=torch.int64, device=self.dev)
-            self.out_eidx = torch.empty((2, max(cap, 1)), dtype=torch.int64, device=self.dev)
-            self.out_esrc = torch.empty((max(cap, 1),), dtype=torch.int64, device=self.dev)
+            # (the torch path keeps one sink slot behind the capacity: where the entries of an overflowing step are dropped)
+            sink = 0 if self.dev.type == "cuda" else 1
+            self._eidx_buf = torch.empty((2, max(cap, 1) + sink), dtype=torch.int64, device=self.dev)
+            self._esrc_buf = torch.empty((max(cap, 1) + sink,), dtype=torch.int64, device=self.dev)
+            self.out_eidx = self._eidx_buf[:, :max(cap, 1)]
+            self.out_esrc = self._esrc_buf[:max(cap, 1)]
             self._row_off_c = (C.c_int64 * (self.world + 1))(*self.row_off)
             self._lanes = torch.arange(self.edge_cap, dtype=torch.int64, device=self.dev) if self.dev.type != "cuda" else None
 
@@ -113,6 +157,7 @@ class Collator:
             raise RuntimeError(f"Collator: rank {self.rank} owns {rows} rows, got {nodes.size(0)}")
         head, w_nodes, w_eptr, w_eidx, w_esrc = self._views
         head[1:2].copy_(edge_ptr[rows:rows + 1])
+        torch.maximum(self.max_total, edge_ptr[rows:rows + 1], out=self.max_total)
         w_nodes[:rows].copy_(nodes)
         w_eptr[:rows + 1].copy_(edge_ptr)                      # values < 2^32: stored as the low 32 bits
         n = min(self.edge_cap, edge_index.size(1))             # whatever lies beyond the step's total is never read
@@ -153,7 +198,7 @@ class Collator:
             check(lib.ugs_collate_unpack(self.inbox.data_ptr(), self.world, self._row_off_c, self.k, self.nb, self.eb, self.sb,
                                          self.rows_cap, self.edge_cap, self.out_nodes.data_ptr(), self.out_eidx.data_ptr(),
                                          self.out_eidx.stride(0), self.out_eptr.data_ptr(), self.out_esrc.data_ptr(),
-                                         torch.cuda.current_stream(self.dev).cuda_stream))
+                                         self.max_total.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream))
         else:
             self._unpack_torch()
         return self.out_nodes, self.out_eidx, self.out_eptr, self.out_esrc
@@ -170,14 +215,25 @@ class Collator:
             lp = w_eptr[:rows].to(torch.int64) & 0xFFFFFFFF
             torch.add(lp, off, out=self.out_eptr[r0:r1])
             if self.edge_cap:
-                idx = self._lanes + off
+                idx = torch.clamp(self._lanes + off, max=self.out_esrc.numel())      # beyond the capacity (overflow): the sink slot
                 blk = w_eidx.to(torch.int64)
                 if self.ed == torch.uint8:
                     blk = blk & 0xFF
-                self.out_eidx.index_copy_(1, idx, blk)
-                self.out_esrc.index_copy_(0, idx, w_esrc.to(torch.int64))
+                self._eidx_buf.index_copy_(1, idx, blk)
+                self._esrc_buf.index_copy_(0, idx, w_esrc.to(torch.int64))
             off = off + head[1]
+            torch.maximum(self.max_total, head[1:2], out=self.max_total)
         self.out_eptr[self.total_rows:].copy_(off.reshape(1))
+
+    # -- capacity check (lazy: one host synchronisation per call) ---------------------------------------------------------------
+    def overflowed(self):
+        """True if some step so far had a per-rank edge total above edge_cap (that step's batch was truncated: invalid)."""
+        return int(self.max_total.item()) > self.edge_cap
+
+    def check(self):
+        t = int(self.max_total.item())
+        if t > self.edge_cap:
+            raise RuntimeError(f"Collator: a rank produced {t} edge entries in one step, capacity is {self.edge_cap}: that step's batch is invalid")
 
     def collate(self, local):
         self.pack(local)
@@ -198,10 +254,11 @@ def collate(local, k, mode, node_id_bound, edge_id_bound, col_bound, group=None,
     dist.all_gather_into_tensor(sizes, mine, group=group)
     sizes = sizes.cpu()
     total_rows, edge_cap = int(sizes[:, 0].sum()), int(sizes[:, 1].max())
-    spans = [shard_range(total_rows, r, world)[1] for r in range(world)]
-    if spans != sizes[:, 0].tolist():
-        raise RuntimeError("collate: the ranks' row counts are not the shard_range split of their sum")
-    c = Collator(total_rows, k, mode, node_id_bound, edge_id_bound, col_bound, edge_cap, dev, group=group, dst=dst, all_ranks=all_ranks)
+    row_off = [0]
+    for c_ in sizes[:, 0].tolist():                            # any contiguous split in rank order (equal or weighted)
+        row_off.append(row_off[-1] + int(c_))
+    c = Collator(total_rows, k, mode, node_id_bound, edge_id_bound, col_bound, edge_cap, dev, group=group, dst=dst, all_ranks=all_ranks,
+                 row_off=row_off)
     res = c.collate(local)
     if res is None:
         return None
@@ -222,7 +279,7 @@ def default_row_sampler(edge_index, ptr, k):
 
 
 def sample_batch_sharded(edge_index, ptr, m_per_graph, k, mode="sample", seed=42, group=None, dst=0, all_ranks=True,
-                         row_sampler=None):
+                         row_sampler=None, weights=None):
     """sample_batch with the G*m rows sharded over the ranks of `group`; returns the reference's 5-tuple
     (nodes, edge_index, edge_ptr, sample_ptr, edge_src_global) on `dst` (or on all ranks), identical to the
     single-process result.  `row_sampler(m, mode, seed, row_begin, row_count)` produces a rank's rows; the default is
@@ -231,7 +288,7 @@ def sample_batch_sharded(edge_index, ptr, m_per_graph, k, mode="sample", seed=42
     rank = dist.get_rank(group)
     G = int(ptr.numel()) - 1
     rows = max(G, 0) * int(m_per_graph)
-    begin, count = shard_range(rows, rank, world)
+    begin, count = shard_range(rows, rank, world, weights)     # weights: the same list on every rank (shard_offsets)
     if row_sampler is None:
         row_sampler = default_row_sampler(edge_index, ptr, k)
     local = row_sampler(int(m_per_graph), mode, int(seed), begin, count)

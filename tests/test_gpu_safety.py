@@ -133,10 +133,12 @@ def test_one_plan_on_two_streams():
         assert np.array_equal(a.numpy(), b)
 
 
-@pytest.mark.parametrize("mode,world", [("sample", 3), ("global", 2), ("graph", 5)])
-def test_collation_kernels_equal_the_torch_path_and_the_oracle(mode, world):
+@pytest.mark.parametrize("mode,world,weights", [("sample", 3, None), ("global", 2, None), ("graph", 5, None),
+                                                ("sample", 3, [0.4, 1.0, 1.2]), ("global", 2, [0.0, 1.0]), ("graph", 5, [0.7, 1, 1, 1.1, 0.9])])
+def test_collation_kernels_equal_the_torch_path_and_the_oracle(mode, world, weights):
     """ugs_collate_unpack (HIP) against the torch-operation path of the same Collator and against the single-process result:
-    `world` ranks' messages are packed on the GPU, placed in the destination's inbox by hand (no process group needed), unpacked."""
+    `world` ranks' messages are packed on the GPU, placed in the destination's inbox by hand (no process group needed), unpacked.
+    Equal and uneven (destination-aware) row ranges; then a capacity below one rank's total: reported, nothing written out of bounds."""
     import torch
     import oracle
     import ugs_workloads as wl
@@ -149,9 +151,11 @@ def test_collation_kernels_equal_the_torch_path_and_the_oracle(mode, world):
     for seed in (1, 2):
         full = oracle.sample_batch(ei, ptr, m, k, mode, seed)
         nodes, eidx, eptr, _, esrc = full
-        spans = [ud.shard_range(G * m, r, world) for r in range(world)]
+        row_off = ud.shard_offsets(G * m, world, weights)
+        spans = [(row_off[r], row_off[r + 1] - row_off[r]) for r in range(world)]
         cap = max(int(eptr[b + c] - eptr[b]) for b, c in spans) + 5
-        mk = lambda r, d: ud.Collator(G * m, k, mode, node_bound, max(node_bound, m * k), ei.shape[1], cap, d, dst=0, world=world, rank=r)
+        mk = lambda r, d, cap_=cap: ud.Collator(G * m, k, mode, node_bound, max(node_bound, m * k), ei.shape[1], cap_, d, dst=0, world=world, rank=r,
+                                                row_off=row_off)
         dst_gpu, dst_cpu = mk(0, dev), mk(0, "cpu")
         for r, (b, c) in enumerate(spans):
             e0, e1 = int(eptr[b]), int(eptr[b + c])
@@ -167,6 +171,28 @@ def test_collation_kernels_equal_the_torch_path_and_the_oracle(mode, world):
         assert int(got[2][-1]) == tot == int(ref[2][-1])
         for g, r_, w in ((got[0], ref[0], nodes), (got[2], ref[2], eptr), (got[1][:, :tot], ref[1][:, :tot], eidx), (got[3][:tot], ref[3][:tot], esrc)):
             assert np.array_equal(g, w) and np.array_equal(r_, w)
+        assert not dst_gpu.overflowed() and not dst_cpu.overflowed()
+        # capacity 3 entries short of the fullest rank: that rank's message is truncated, the destination finds out from the headers
+        short = cap - 5 - 3
+        if short > 0:
+            sg, sc = mk(0, dev, short), mk(0, "cpu", short)
+            guard = torch.full((64,), -12345, dtype=torch.int64, device=dev)              # allocated right behind the output buffers
+            for r, (b, c) in enumerate(spans):
+                e0, e1 = int(eptr[b]), int(eptr[b + c])
+                local = (torch.from_numpy(nodes[b:b + c].copy()), torch.from_numpy(eidx[:, e0:e1].copy()), torch.from_numpy((eptr[b:b + c + 1] - e0).copy()),
+                         torch.from_numpy(esrc[e0:e1].copy()))
+                packer = mk(r, dev, short)
+                msg = packer.pack(tuple(t.to(dev) for t in local))
+                assert packer.overflowed() == (e1 - e0 > short)
+                sg.inbox[r].copy_(msg)
+                sc.inbox[r].copy_(msg.cpu())
+            o_g, o_c = sg.unpack(), sc.unpack()
+            torch.cuda.synchronize()
+            assert sg.overflowed() and sc.overflowed() and int(sg.max_total.item()) == int(sc.max_total.item()) == cap - 5
+            assert np.array_equal(o_g[0].cpu().numpy(), nodes) and np.array_equal(o_c[0].numpy(), nodes)    # the rows themselves are intact
+            assert bool((guard == -12345).all())
+            with pytest.raises(RuntimeError):
+                sg.check()
 
 
 @pytest.mark.timeout(300)
@@ -185,5 +211,10 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
                         "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["global_rows"] == 100_000 and line["config"]["rows_per_gpu"] == 50_000
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["global_rows"] == 100_000
+    # the destination-aware split (default --dst-rows auto): two calibration rounds, the first on the equal split; the ranks' rows cover the batch
+    pr, cal = line["per_rank"], line["split_calibration"]
+    assert len(cal) == 2 and cal[0]["rows"] == [50_000, 50_000] and sum(cal[1]["rows"]) == 100_000
+    assert [p_["rank"] for p_ in pr] == [0, 1] and sum(p_["rows"] for p_ in pr) == 100_000 and line["config"]["rows_per_gpu"] == pr[0]["rows"]
+    assert pr[0]["walk_share"] == 80 and pr[1]["walk_share"] == 100 and all(p_["walk_ms"] > 0 for p_ in pr)
     assert line["collate_ms_per_step"] is not None and line["extras"]["weak_scaling"]["global_rows"] == 200_000

@@ -1,48 +1,106 @@
-"""Rank 0 of an 8-rank strong-scaled C5 job emulated on ONE GPU: its shard's walk/scan/fill on the main stream, and beside it the
-collation of the WHOLE 1M-row batch (pack of the own shard, a device copy standing in for the 7 received messages, unpack of 8
-messages) on a side stream, double-buffered like bench.py.  Reports steady-state ms per step for walk shares and shard sizes."""
-import sys, time
-sys.path.insert(0, "ss-gnn_amd")
-import torch, numpy as np, ugs_sampler, ugs_workloads as wl
-from ugs_sampler import distributed as ud
+"""The two kinds of rank of an 8-rank strong-scaled C5 job (BASELINE config 5: 1M rows split over 8 GPUs), each emulated on ONE GPU:
+
+  destination (rank 0)  its shard's walk / scan / fill on the main stream and, beside it on a side stream, the collation of the WHOLE
+                        1M-row batch: pack of the own shard, a device copy standing in for the 7 messages arriving over xGMI, unpack
+                        of 8 messages -- double-buffered exactly like bench.py (a buffer set is free once it has been packed);
+  other ranks           their shard's walk / scan / fill and the pack of their message (the send itself is a DMA).
+
+The job's step time is the slower of the two.  Run for the OLD split (equal shards, every rank's walk on 80 % of each CU: round 2)
+and for destination-aware splits (rank 0 fewer rows, the others the whole CU): writes gpurun_out/r03_rank0_emulation.json, which is
+kept under profiles/.  usage: python tools/rank0_emulation.py [--world 8]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ss-gnn_amd"))
+import torch                      # noqa: E402
+import ugs_sampler                # noqa: E402
+import ugs_workloads as wl        # noqa: E402
+from ugs_sampler import distributed as ud   # noqa: E402
+
+WORLD = int(sys.argv[sys.argv.index("--world") + 1]) if "--world" in sys.argv else 8
 ei, ptr, m, k = wl.workload("c5_er_1m")
 dev = torch.device("cuda:0")
 plan = ugs_sampler.Plan.from_batch(torch.from_numpy(ei), torch.from_numpy(ptr), k)
 total = m
-def run(share, rows, steps=24, collate=True):
+node_bound = int(ptr[-1])
+
+
+def run(share, rows0, rank, steps=24, collate=True):
+    """steady-state ms per step of `rank` (0 = destination) when rank 0 samples rows0 rows and the others share the rest equally"""
+    w0 = rows0 * (WORLD - 1) / (total - rows0)
+    row_off = ud.shard_offsets(total, WORLD, [w0] + [1.0] * (WORLD - 1))
+    begin, rows = row_off[rank], row_off[rank + 1] - row_off[rank]
     plan.set_walk_share(share)
-    nodes0, eptr0, tot = plan.walk(m, "sample", 1, 0, rows, sync=True)
-    cap = int(tot * 1.15) + 1024
-    col = ud.Collator(total, k, "sample", int(ptr[-1]), max(int(ptr[-1]), m * k), ei.shape[1], int(cap * (total / 8) / rows) + 1024, dev, world=8, rank=0)
-    rows_c = col.rows                                               # the collator's own (even) shard: the message format is fixed
-    bufs = []
-    for b in range(2):
-        n = torch.empty((rows_c, k), dtype=torch.int64, device=dev); p = torch.empty((rows_c + 1,), dtype=torch.int64, device=dev)
-        e = torch.empty((2, col.edge_cap), dtype=torch.int64, device=dev); s = torch.empty((col.edge_cap,), dtype=torch.int64, device=dev)
-        bufs.append((n, p, e, s))
-    side = torch.cuda.Stream()
-    main = torch.cuda.current_stream()
-    ev_fill = [torch.cuda.Event(), torch.cuda.Event()]; ev_col = [torch.cuda.Event(), torch.cuda.Event()]
+    _, _, tot = plan.walk(m, "sample", 1, begin, rows, sync=True)
+    rows_cap = max(row_off[r + 1] - row_off[r] for r in range(WORLD))
+    cap = int(tot * 1.1 * rows_cap / rows) + 4096
+    col = ud.Collator(total, k, "sample", node_bound, max(node_bound, m * k), ei.shape[1], cap, dev, world=WORLD, rank=rank, dst=0, row_off=row_off)
+    bufs = [(torch.empty((rows, k), dtype=torch.int64, device=dev), torch.empty((rows + 1,), dtype=torch.int64, device=dev),
+             torch.empty((2, cap), dtype=torch.int64, device=dev), torch.empty((cap,), dtype=torch.int64, device=dev)) for _ in range(2)]
+    side, main = torch.cuda.Stream(), torch.cuda.current_stream()
+    ev_fill = [torch.cuda.Event(), torch.cuda.Event()]
+    ev_packed = [torch.cuda.Event(), torch.cuda.Event()]
+    if rank == 0:                                    # realistic inbox: 8 valid messages (the other ranks' shards are about this large)
+        n, p, e, s = bufs[0]
+        plan.walk(m, "sample", 7, begin, rows, out=(n, p), sync=False)
+        plan.fill(m, n, p, None, "sample", begin, out=(e, s))
+        col.pack((n, e, p, s))
+        torch.cuda.synchronize()
+
     def step(i):
         b = i & 1
         n, p, e, s = bufs[b]
-        main.wait_event(ev_col[b])                                  # the collation that read these buffers two steps ago
-        # the shard that is WALKED has `rows` rows (uneven split); what is packed is the collator's fixed shard shape
-        plan.walk(m, "sample", 100 + i, 0, rows, out=(n[:rows] if rows <= rows_c else None, p[:rows + 1] if rows <= rows_c else None), sync=False) if rows <= rows_c else plan.walk(m, "sample", 100 + i, 0, rows_c, out=(n, p), sync=False)
-        plan.fill(m, n[:min(rows, rows_c)], p[:min(rows, rows_c) + 1], None, "sample", 0, out=(e, s))
+        main.wait_event(ev_packed[b])
+        plan.walk(m, "sample", 100 + i, begin, rows, out=(n, p), sync=False)
+        plan.fill(m, n, p, None, "sample", begin, out=(e, s))
         ev_fill[b].record(main)
         if collate:
             with torch.cuda.stream(side):
                 side.wait_event(ev_fill[b])
                 col.pack((n, e, p, s))
-                col.inbox.copy_(col.msg.unsqueeze(0).expand(8, -1))   # stands in for the 7 messages arriving over xGMI
-                col.unpack()
-                ev_col[b].record(side)
-    for i in range(4): step(i)
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for i in range(4, 4 + steps): step(i)
+                ev_packed[b].record(side)
+                if rank == 0:
+                    col.inbox[1:].copy_(col.msg.unsqueeze(0).expand(WORLD - 1, -1))   # stands in for the WORLD-1 messages arriving over xGMI
+                    col.inbox[0].copy_(col.msg)
+                    col.unpack()
+
+    for i in range(4):
+        step(i)
     torch.cuda.synchronize()
-    return (time.perf_counter() - t) / steps * 1e3
-for share in (100, 80):
-    for rows in (125000, 100000):
-        print(f"share {share:3d}  rows {rows}:  walk-only {run(share, rows, collate=False):.3f} ms/step   with the batch's collation {run(share, rows):.3f} ms/step", flush=True)
+    t = time.perf_counter()
+    for i in range(4, 4 + steps):
+        step(i)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t) / steps * 1e3
+    assert not col.overflowed()
+    return round(ms, 4), rows
+
+
+out = {"workload": "c5_er_1m", "world": WORLD, "global_rows": total, "cases": []}
+equal = total // WORLD
+# old split (round 2): equal shards, every rank's walk at 80 %
+d_ms, d_rows = run(80, equal, 0)
+o_ms, o_rows = run(80, equal, 1)
+out["old_equal_split_share80_everywhere"] = {"rank0_rows": d_rows, "rank0_ms": d_ms, "other_rows": o_rows, "other_ms": o_ms, "step_ms": max(d_ms, o_ms),
+                                             "k_subgraphs_per_s": round(total / max(d_ms, o_ms) * 1e3, 1)}
+print(json.dumps(out["old_equal_split_share80_everywhere"]), flush=True)
+for share in (80, 100):
+    for rows0 in (equal, int(equal * 0.92), int(equal * 0.88), int(equal * 0.84), int(equal * 0.80)):
+        d_ms, d_rows = run(share, rows0, 0)
+        d_alone, _ = run(share, rows0, 0, collate=False)
+        o_ms, o_rows = run(100, rows0, 1)
+        case = {"rank0_walk_share": share, "rank0_rows": d_rows, "rank0_ms": d_ms, "rank0_ms_without_collation": d_alone, "other_rows": o_rows,
+                "other_ms_share100": o_ms, "step_ms": max(d_ms, o_ms), "k_subgraphs_per_s": round(total / max(d_ms, o_ms) * 1e3, 1)}
+        out["cases"].append(case)
+        print(json.dumps(case), flush=True)
+best = min(out["cases"], key=lambda c: c["step_ms"])
+out["best"] = best
+out["note"] = ("one GPU plays one rank at a time; the 7 incoming messages are a device copy; whether RCCL's receive kernels find wave slots beside "
+               "the walk is not covered (needs a multi-GPU node)")
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+with open(os.path.join(ROOT, "gpurun_out", "r03_rank0_emulation.json"), "w") as f:
+    json.dump(out, f, indent=1)
+print("best:", json.dumps(best))
