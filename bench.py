@@ -15,9 +15,11 @@ Erdos-Renyi graph |V|=1M, 20M columns, k=8, batch = 1M samples.
   strong scaling (default): the N ranks split THE batch -- rank r samples rows [r*B/N, (r+1)*B/N) (legal
       because row i depends only on (seed, i), reference src/sampler.cpp:158-161) -- and the batch is collated on rank 0;
   weak scaling: every rank adds B rows of the same job (N*B rows per step), collated on rank 0.
-For N > 1 every step collates the batch on rank 0 over RCCL (ugs_sampler.distributed.Collator: no host round trip) on a side
-stream, double-buffered, so the collation of batch s overlaps the sampling of batch s+1; all K collations are inside the
-timed region.  The seed changes every step (42 + step) so no step can reuse a previous step's output.
+For N > 1 every step collates the batch on rank 0 over RCCL (ugs_sampler.distributed.Collator: no host round trip): every rank
+packs its rows behind its fill, the gather runs on a side stream while the next batch is sampled, and rank 0 unpacks batch s
+behind the sampling of batch s+1 (class Job); all K collations are inside the timed region.  Rank 0 therefore does more per
+step than the others and is given fewer rows (--dst-rows auto: measured in the warm-up).  The seed changes every step
+(42 + step) so no step can reuse a previous step's output.
 """
 import argparse
 import json
@@ -190,7 +192,15 @@ def split_algorithmic_bytes(nodes, edge_ptr, k, deg):
 
 
 class Job:
-    """One sharded sampling job on this rank: buffers, the step function and (N > 1) the collation on a side stream."""
+    """One sharded sampling job on this rank: buffers, the step function and (N > 1) its part of the collation.
+
+    Stream plan of a step (N > 1).  Everything a rank computes runs on its MAIN stream, back to back: walk, scan, fill of batch i;
+    on the destination the unpack of batch i-1 (whose messages arrived while batch i was being sampled); the pack of batch i.
+    Only the exchange itself (RCCL gather) runs on a side stream, behind the pack.  Round 2 ran pack and unpack on the side stream
+    BESIDE the next walk: the walk kernels are persistent grids that hold their share of every CU to the end, so the collation got
+    what was left (a fifth of the machine) and took up to a whole step -- the steady state then depended on how the two streams
+    happened to interleave (rank-0 emulation: 0.76 ... 1.03 ms per step for neighbouring shard sizes).  Serial on one stream the
+    same kernels take 0.2 ms at full rate, and the step time is the sum of its parts: what the split calibration needs."""
 
     def __init__(self, torch, dist, ud, plan, args, G, m_total, k, rank, world, dev, node_bound, n_cols, use_collate, weights=None):
         self.torch, self.plan, self.args, self.k, self.m_total = torch, plan, args, k, m_total
@@ -198,71 +208,77 @@ class Job:
         self.row_off = ud.shard_offsets(self.total_rows, world, weights)      # the same list on every rank
         self.row_begin, self.row_count = self.row_off[rank], self.row_off[rank + 1] - self.row_off[rank]
         self.use_collate = use_collate
-        nsets = 2 if use_collate else 1       # double buffering: step s samples into set s%2 while set (s-1)%2 is collated
-        self.nsets = nsets
+        self.nsets = 1                        # the pack follows the fill on the same stream: one buffer set
         rc = self.row_count
-        self.nodes = [torch.empty((rc, k), dtype=torch.int64, device=dev) for _ in range(nsets)]
-        self.eptr = [torch.empty((rc + 1,), dtype=torch.int64, device=dev) for _ in range(nsets)]
+        self.nodes = [torch.empty((rc, k), dtype=torch.int64, device=dev)]
+        self.eptr = [torch.empty((rc + 1,), dtype=torch.int64, device=dev)]
         # edge capacity from one synchronous probe step (+5%); identical on every rank
         _, _, tot = plan.walk(m_total, args.mode, 41, self.row_begin, rc, out=(self.nodes[0], self.eptr[0]), sync=True)
         cap_t = torch.tensor([int(tot * 1.05) + 4096], dtype=torch.int64, device=dev)
         if world > 1:
             dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
         self.cap = int(cap_t.item())
-        self.eidx = [torch.empty((2, self.cap), dtype=torch.int64, device=dev) for _ in range(nsets)]
-        self.esrc = [torch.empty((self.cap,), dtype=torch.int64, device=dev) for _ in range(nsets)]
+        self.eidx = [torch.empty((2, self.cap), dtype=torch.int64, device=dev)]
+        self.esrc = [torch.empty((self.cap,), dtype=torch.int64, device=dev)]
         self.main = torch.cuda.current_stream()
         if use_collate:
             self.side = torch.cuda.Stream(device=dev)
             self.collator = ud.Collator(self.total_rows, k, args.mode, node_bound, max(node_bound, m_total * k), n_cols, self.cap, dev, dst=0,
                                         row_off=self.row_off)
-            self.ev_sampled = [torch.cuda.Event() for _ in range(nsets)]
-            self.ev_collated = [torch.cuda.Event() for _ in range(nsets)]
-            self.collated_once = [False] * nsets
-            self.cev = []                      # (start, end) events of every collation on the side stream
+            self.ev_packed, self.ev_exchanged = torch.cuda.Event(), torch.cuda.Event()
+            self.in_flight = False             # a batch has been packed and handed to the exchange, not unpacked yet
+            self.cev = []                      # (start, end) events of this rank's collation work (unpack + pack) on the main stream
         self.totals = None
 
     def sample(self, i):
-        """walk + scan + fill of step i into buffer set i % nsets (asynchronous, main stream)"""
-        b = i % self.nsets
-        if self.use_collate and self.collated_once[b]:
-            self.main.wait_event(self.ev_collated[b])            # the set is free once its previous batch has been packed
-        self.plan.walk(self.m_total, self.args.mode, 42 + i, self.row_begin, self.row_count, out=(self.nodes[b], self.eptr[b]), sync=False)
-        self.plan.fill(self.m_total, self.nodes[b], self.eptr[b], None, self.args.mode, self.row_begin, out=(self.eidx[b], self.esrc[b]))
+        """walk + scan + fill of step i (asynchronous, main stream)"""
+        self.plan.walk(self.m_total, self.args.mode, 42 + i, self.row_begin, self.row_count, out=(self.nodes[0], self.eptr[0]), sync=False)
+        self.plan.fill(self.m_total, self.nodes[0], self.eptr[0], None, self.args.mode, self.row_begin, out=(self.eidx[0], self.esrc[0]))
         if self.totals is not None:
-            self.totals[i] = self.eptr[b][-1]
-        if self.use_collate:
-            self.ev_sampled[b].record(self.main)
+            self.totals[i] = self.eptr[0][-1]
+
+    def _unpack_previous(self):
+        """the batch whose exchange is in flight: wait for its messages (stream-side), unpack it on the destination"""
+        res = None
+        if self.in_flight:
+            self.main.wait_event(self.ev_exchanged)              # also: this rank's message buffer is free again
+            res = self.collator.unpack()
+            self.in_flight = False
+        return res
 
     def collate_step(self, i, timed, exchange=True):
-        """the one exchange step: collate batch i on rank 0 (side stream, overlaps the sampling of batch i+1).  exchange=False
-        (calibration): this rank's own part only -- pack, and on the destination the unpack of the messages already in its inbox"""
-        torch, b = self.torch, i % self.nsets
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(self.ev_sampled[b])
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(self.side)
-            self.collator.pack((self.nodes[b], self.eidx[b], self.eptr[b], self.esrc[b]))
-            self.ev_collated[b].record(self.side)                # the buffer set is free as soon as it has been PACKED: the exchange
-            if exchange:
-                self.collator.exchange()                         # and the unpack may lag behind the sampling without stalling it
-            res = self.collator.unpack()
-            if timed:
-                e1.record(self.side)
-                self.cev.append((e0, e1))
-        self.collated_once[b] = True
+        """this rank's part of the one exchange step, after sample(i): unpack batch i-1 (destination), pack batch i, start its
+        exchange.  Returns the collated batch i-1 on the destination.  exchange=False (calibration): the same work without the
+        collective -- the destination unpacks the messages already in its inbox."""
+        torch = self.torch
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(self.main)
+        res = self._unpack_previous()
+        self.collator.pack((self.nodes[0], self.eidx[0], self.eptr[0], self.esrc[0]))
+        self.ev_packed.record(self.main)
+        if timed:
+            e1.record(self.main)
+            self.cev.append((e0, e1))
+        if exchange:
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ev_packed)
+                self.collator.exchange()
+                self.ev_exchanged.record(self.side)
+        else:
+            self.ev_exchanged.record(self.main)
+        self.in_flight = True
         return res
 
     def run_steps(self, first, count, timed=False, exchange=True):
-        """`count` complete steps: every batch sampled AND (multi-GPU) collated inside the call"""
+        """`count` complete steps: every batch sampled AND (multi-GPU) collated inside the call; returns the last collated batch"""
         res = None
         for i in range(first, first + count):
             self.sample(i)
-            if self.use_collate and i > first:
-                self.collate_step(i - 1, timed, exchange)
+            if self.use_collate:
+                self.collate_step(i, timed, exchange)
         if self.use_collate and count > 0:
-            res = self.collate_step(first + count - 1, timed, exchange)
+            res = self._unpack_previous()                        # the last batch: its exchange is exposed, as in any pipeline's drain
             self.side.synchronize()
         return res
 
@@ -544,8 +560,9 @@ def main():
            "config": {"workload": args.workload, "graphs": G, "columns": int(ei.shape[1]), "k": k, "rows_per_gpu": row_count,
                       "global_rows": total_rows, "mode": args.mode, "sharding": f"rows{world}" if world > 1 else "none",
                       "collate": "gather to rank 0 over RCCL every step (fixed-size narrowed messages, device-side offsets, no host round trip), "
-                                 f"overlapped with the next step's sampling (walk kernels on {args.walk_share}% of each CU on the destination, "
-                                 f"{args.walk_share_others}% elsewhere); rows split {args.dst_rows}" if use_collate else "none (single GPU)"},
+                                 f"the gather overlaps the next step's sampling, rank 0 unpacks one step behind (walk kernels on {args.walk_share}% of each "
+                                 f"CU on the destination so that RCCL's kernels find wave slots, {args.walk_share_others}% elsewhere); rows split {args.dst_rows}"
+                                 if use_collate else "none (single GPU)"},
            "collate_ms_per_step": round(collate_ms, 4) if collate_ms is not None else None,
            "per_rank": per_rank, "split_calibration": calibration,
            "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_port": cpu_port if cpu_baseline else None,

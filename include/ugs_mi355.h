@@ -105,6 +105,12 @@ int ugs_job_cancel(ugs_job *job);
  * reference src/ugs_sampler_batch_extension.cpp:15-38).  Clearing it is the equivalent of a fresh process. */
 int ugs_cache_clear(void);
 int ugs_cache_stats(int64_t *size, int64_t *hits, int64_t *misses);
+/* The input side of ugs_sample_batch_begin / ugs_plan_create_batch for batches of small graphs runs on the device (SURVEY.md
+ * 8(f) N4): one pass over edge_index + ptr replaces the reference's per-graph slicing (src/ugs_sampler_batch_extension.cpp:41-75),
+ * hashing (include/cache.hpp:81-109) and CSR construction (src/preproc.cpp:32-86); the host replays the LRU on the G keys that
+ * come back.  Counters since process start: plans built that way / calls that took the general (host) path instead
+ * (UGS_DEVICE_BATCH=0, non-monotone ptr, a graph with more than 2048 vertices or 1000 columns). */
+int ugs_batch_pass_stats(int64_t *device_plans, int64_t *general_path);
 
 /* ---- device-resident plans: the batch (or single graph) preprocessed once and kept in HBM, sampled many times,
  *      optionally over a sub-range of the G*m result rows (multi-GPU sharding: row b = g*m + i depends only on

@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "libugs_mi355.so")
-SRCS = [os.path.join(HERE, "ugs_kernels.hip"), os.path.join(HERE, "ugs_eps.hip"), os.path.join(HERE, "ugs_preproc.hip"), os.path.join(HERE, "ugs_collate.hip"), os.path.join(HERE, "ugs_host.cpp"),
+SRCS = [os.path.join(HERE, "ugs_kernels.hip"), os.path.join(HERE, "ugs_eps.hip"), os.path.join(HERE, "ugs_preproc.hip"), os.path.join(HERE, "ugs_collate.hip"), os.path.join(HERE, "ugs_batch.hip"), os.path.join(HERE, "ugs_host.cpp"),
         os.path.join(HERE, "ugs_apx.cpp"), os.path.join(HERE, "ugs_apx_gpu.hip")]
 HDRS = [os.path.join(HERE, "ugs_device.h"), os.path.join(HERE, "ugs_apx_common.h"), os.path.join(HERE, "..", "..", "include", "ugs_mi355.h")]
 DEPS = SRCS + HDRS

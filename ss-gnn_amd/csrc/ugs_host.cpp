@@ -27,7 +27,7 @@
 #include <vector>
 
 struct ugs_plan;
-namespace { void plan_unref(ugs_plan *p); }
+namespace { void plan_unref(ugs_plan *p); void arena_release(int dev, int64_t roots_off, int64_t n_roots, int64_t via_off, int64_t n_via); }
 
 // launcher of the epsilon_uniform kernels (ugs_eps.hip)
 struct UgsEpsLaunch {
@@ -92,7 +92,15 @@ struct Graph {
     UgsDevPre *devpre = nullptr;      // device CSR left by preprocess_on_device for the FIRST plan assembled from this graph
     int devpre_dev = -1;
     UgsDevPre *take_devpre(int dev) { std::lock_guard<std::mutex> lk(pre_mu); if (!devpre || devpre_dev != dev) return nullptr; UgsDevPre *d = devpre; devpre = nullptr; return d; }
-    ~Graph() { if (plan) plan_unref(plan); if (devpre) ugs_devpre_free(devpre); }
+    // root records / viable list of this graph resident in a device's arena (device batch pass: plans of new combinations of
+    // known graphs point at them instead of copying them); offsets in elements, -1 = none
+    struct DevRoots { int dev; int64_t roots_off, n_roots, via_off, n_via; };
+    std::vector<DevRoots> dev_roots;
+    ~Graph() {
+        if (plan) plan_unref(plan);
+        if (devpre) ugs_devpre_free(devpre);
+        for (auto &d : dev_roots) arena_release(d.dev, d.roots_off, d.n_roots, d.via_off, d.n_via);
+    }
 };
 
 // CSR of the symmetrised multigraph, entries in column order (both endpoints of column j, u's row first).
@@ -454,6 +462,7 @@ struct ugs_plan {
     int stg_m = 0, stg_k = 0;
     int64_t gws_groups = 0, gws_words = 0;
     int gcap = 0, ghs = 0, gbcap = 0, gpcap = 0;
+    std::vector<std::shared_ptr<void>> keep;   // device-built plans point into their graphs' arena entries: the graphs live as long as the plan
     UgsLaunchInfo last_walk{nullptr, 0, 0, 0};
     UgsLaunchInfo last_fill{nullptr, 0, 0, 0};
     int64_t last_overflow = 0;
@@ -903,6 +912,245 @@ int plan_leave(ugs_plan *plan, hipStream_t s) {
     return UGS_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Device batch pass (batches of small graphs; kernels: ugs_batch.hip).
+//
+// A call with a batch that was not seen before as a whole -- in a training loop: every shuffled mini-batch, a new combination
+// of graphs the LRU already knows -- no longer walks the columns on the host.  edge_index and ptr are uploaded, one device pass
+// slices the batch, computes every graph's LRU key (the reference's FNV-1a, include/cache.hpp:81-109) and writes the plan's
+// rowptr / adj / adjf straight into HBM in the reference's CSR order (src/preproc.cpp:32-86); 16 bytes per graph come back.
+// The host replays the LRU on those keys (same lookups, same order, same eviction as the general path) and points every
+// graph's descriptor at the root records its cached preprocessing keeps in the device's arena.  Only a graph the LRU does not
+// know is sliced and preprocessed on the host (its column span comes back with its key), once.
+//
+// Applicable when ptr is non-decreasing (disjoint node ranges) and every graph has at most UGS_BATCH_PASS_MAX_N vertices and
+// UGS_BATCH_PASS_MAX_COLS columns -- up to there the key covers a graph's whole content, so a cached graph with the same key
+// has exactly the CSR the pass has just built (beyond, the reference's key samples the columns and the general path below
+// reproduces what it then does: it samples from the CACHED graph).  Everything else takes the general path.
+// UGS_DEVICE_BATCH=0 switches the pass off, =1 is the default.
+// ---------------------------------------------------------------------------------------------------------------
+struct RootArena {
+    UgsRootRec *roots = nullptr; int64_t roots_cap = 0, roots_used = 0;
+    int2 *via = nullptr; int64_t via_cap = 0, via_used = 0;
+    std::map<int64_t, std::vector<int64_t>> free_roots, free_via;      // exact-size reuse of released entries
+    void *pinned = nullptr; size_t pinned_bytes = 0;                    // staging of the keys coming back
+    std::mutex call_mu;                                                 // one device pass at a time per device (shared staging)
+};
+std::mutex g_arena_mu;
+std::map<int, RootArena *> &g_arenas = *new std::map<int, RootArena *>();
+constexpr int64_t kArenaRoots = (int64_t)2 << 20, kArenaVia = (int64_t)1 << 20;     // 48 MB of root records + 8 MB of viable entries per device
+
+RootArena *arena_of(int dev) {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    auto it = g_arenas.find(dev);
+    if (it != g_arenas.end()) return it->second;
+    auto *a = new RootArena();
+    if (hipMalloc(reinterpret_cast<void **>(&a->roots), (size_t)kArenaRoots * sizeof(UgsRootRec)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&a->via), (size_t)kArenaVia * sizeof(int2)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (a->roots) (void)hipFree(a->roots);
+        delete a;
+        g_arenas[dev] = nullptr;                                        // no arena on this device: the general path serves every call
+        return nullptr;
+    }
+    a->roots_cap = kArenaRoots; a->via_cap = kArenaVia;
+    g_arenas[dev] = a;
+    return a;
+}
+int64_t arena_take(std::map<int64_t, std::vector<int64_t>> &fl, int64_t &used, int64_t cap, int64_t n) {   // g_arena_mu held
+    if (n <= 0) return 0;
+    auto it = fl.find(n);
+    if (it != fl.end() && !it->second.empty()) { const int64_t off = it->second.back(); it->second.pop_back(); return off; }
+    if (used + n > cap) return -1;
+    const int64_t off = used;
+    used += n;
+    return off;
+}
+void arena_release(int dev, int64_t roots_off, int64_t n_roots, int64_t via_off, int64_t n_via) {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    auto it = g_arenas.find(dev);
+    if (it == g_arenas.end() || !it->second) return;
+    if (n_roots > 0 && roots_off >= 0) it->second->free_roots[n_roots].push_back(roots_off);
+    if (n_via > 0 && via_off >= 0) it->second->free_via[n_via].push_back(via_off);
+}
+// the graph's root records (level 0) or viable list (levels 1, 2) in the device's arena; uploaded once per graph and device
+int graph_dev_roots(Graph &g, int dev, RootArena *ar, hipStream_t s, Graph::DevRoots &out) {
+    std::lock_guard<std::mutex> lk(g.pre_mu);
+    for (auto &d : g.dev_roots) if (d.dev == dev) { out = d; return UGS_OK; }
+    Graph::DevRoots d{dev, -1, 0, -1, 0};
+    if (g.level == 0) d.n_roots = g.n; else d.n_via = (int64_t)g.viable.size();
+    {
+        std::lock_guard<std::mutex> lk2(g_arena_mu);
+        d.roots_off = arena_take(ar->free_roots, ar->roots_used, ar->roots_cap, d.n_roots);
+        d.via_off = arena_take(ar->free_via, ar->via_used, ar->via_cap, d.n_via);
+    }
+    if (d.roots_off < 0 || d.via_off < 0) {
+        if (d.roots_off >= 0 || d.via_off >= 0) arena_release(dev, d.roots_off, d.n_roots, d.via_off, d.n_via);
+        return UGS_E_UNSUPPORTED;                                       // arena full: not an error, the caller takes the general path
+    }
+    if (g.level == 0 && g.n > 0) {
+        std::vector<UgsRootRec> rec((size_t)g.n);
+        for (int64_t vi = 0; vi < g.n; ++vi) {
+            UgsRootRec &r = rec[(size_t)vi];
+            r.prob = g.prob[(size_t)vi]; r.alias = g.alias[(size_t)vi];
+            r.v_self = g.order[(size_t)vi]; r.v_alias = g.order[(size_t)g.alias[(size_t)vi]]; r.pad = 0;
+        }
+        HIP_TRY(hipMemcpyAsync(ar->roots + d.roots_off, rec.data(), rec.size() * sizeof(UgsRootRec), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));                               // `rec` is pageable and goes out of scope
+    } else if (g.level > 0 && !g.viable.empty()) {
+        std::vector<int2> v(g.viable.size());
+        for (size_t t = 0; t < g.viable.size(); ++t) v[t] = make_int2(g.viable[t], g.order[(size_t)g.viable[t]]);
+        HIP_TRY(hipMemcpyAsync(ar->via + d.via_off, v.data(), v.size() * sizeof(int2), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    g.dev_roots.push_back(d);
+    out = d;
+    return UGS_OK;
+}
+
+bool device_batch_enabled() {
+    const char *e = std::getenv("UGS_DEVICE_BATCH");
+    return !(e && e[0] == '0');
+}
+
+constexpr int kBatchNotApplicable = 1;      // positive: not an error code of the C ABI
+std::atomic<int64_t> g_bp_plans{0}, g_bp_fallbacks{0};     // plans built by the device pass / calls it handed to the general path
+
+// Returns UGS_OK with *plan_out set, kBatchNotApplicable (the caller takes the general path; the LRU has not been touched, or
+// its counters have been put back), or an error.
+int device_batch_plan(const int64_t *src, const int64_t *dst, int64_t E, const int64_t *ptr, int64_t G, int k, const DeviceCtx &dc,
+                      bool have_hash, const Hash128 &bh, ugs_plan **plan_out, std::vector<std::pair<uint64_t, int64_t>> &touched) {
+    if (G <= 0 || E <= 0 || G > ((int64_t)1 << 20) || E >= ((int64_t)1 << 24)) return kBatchNotApplicable;
+    std::vector<int64_t> hostv((size_t)(2 * G + 1));                    // ptr[G+1] | rstart[G]: one upload
+    int64_t rows_total = 0, nv = 0;
+    for (int64_t g = 0; g < G; ++g) {
+        const int64_t n = ptr[g + 1] - ptr[g];
+        if (n < 0 || n > UGS_BATCH_PASS_MAX_N) return kBatchNotApplicable;      // non-monotone ptr, or a large graph
+        hostv[(size_t)(G + 1 + g)] = rows_total;
+        if (n > 0 && n >= k) { rows_total += n + 1; nv += n; }
+    }
+    std::memcpy(hostv.data(), ptr, (size_t)(G + 1) * sizeof(int64_t));
+    RootArena *ar = arena_of(dc.id);
+    if (!ar) return kBatchNotApplicable;
+    std::lock_guard<std::mutex> call_lk(ar->call_mu);
+    // ---- one device allocation: the plan's arrays, then the pass's inputs and scratch -------------------------------------------
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + std::max<size_t>(bytes, 8)); return o; };
+    const size_t o_desc = take((size_t)G * sizeof(UgsGraphDesc)), o_row = take((size_t)rows_total * sizeof(int64_t));
+    const size_t o_adj = take((size_t)2 * E * sizeof(int2)), o_adjf = take((size_t)2 * E * sizeof(int2));
+    const size_t o_src = take((size_t)E * 8), o_dst = take((size_t)E * 8), o_ptr = take((size_t)(2 * G + 1) * 8);
+    const size_t o_owner = take((size_t)E * 4), o_cstart = take((size_t)(G + 1) * 4), o_maxdeg = take((size_t)G * 4);
+    // what comes back, contiguous: keys[G] u64 | cnt[G] | jmin[G] | jmax[G] | flag
+    const size_t back_bytes = (size_t)G * 20 + 8;
+    const size_t o_back = take(back_bytes);
+    auto *p = new ugs_plan();
+    if (int rc = pool_get(off, dc.id, p->blob_buf)) { delete p; return rc; }
+    char *base = static_cast<char *>(p->blob_buf.p);
+    auto bail = [&](int rc) { pool_put(p->blob_buf); delete p; return rc; };
+    if (ar->pinned_bytes < back_bytes) {
+        if (ar->pinned) (void)hipHostFree(ar->pinned);
+        ar->pinned = nullptr; ar->pinned_bytes = 0;
+        const size_t want = std::max<size_t>(back_bytes * 2, 1 << 16);
+        if (hipHostMalloc(&ar->pinned, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return bail(kBatchNotApplicable); }
+        ar->pinned_bytes = want;
+    }
+    hipStream_t s = dc.stream;
+    auto *d_src = reinterpret_cast<int64_t *>(base + o_src), *d_dst = reinterpret_cast<int64_t *>(base + o_dst), *d_ptr = reinterpret_cast<int64_t *>(base + o_ptr);
+    auto *d_keys = reinterpret_cast<unsigned long long *>(base + o_back);
+    auto *d_cnt = reinterpret_cast<uint32_t *>(base + o_back + (size_t)G * 8), *d_jmin = d_cnt + G, *d_jmax = d_jmin + G, *d_flag = d_jmax + G;
+    hipError_t e = hipMemcpyAsync(d_src, src, (size_t)E * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_dst, dst, (size_t)E * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ptr, hostv.data(), hostv.size() * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = ugs_launch_batch_pass(d_src, d_dst, E, d_ptr, G, k, reinterpret_cast<int32_t *>(base + o_owner), d_cnt, d_jmin, d_jmax,
+                                                   reinterpret_cast<uint32_t *>(base + o_cstart), d_ptr + (G + 1), reinterpret_cast<int64_t *>(base + o_row),
+                                                   reinterpret_cast<int2 *>(base + o_adj), reinterpret_cast<int2 *>(base + o_adjf), d_keys,
+                                                   reinterpret_cast<uint32_t *>(base + o_maxdeg), d_flag, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(ar->pinned, base + o_back, back_bytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return bail(fail_hip(e, "device batch pass"));
+    const auto *h_keys = static_cast<const unsigned long long *>(ar->pinned);
+    const auto *h_cnt = reinterpret_cast<const uint32_t *>(static_cast<const char *>(ar->pinned) + (size_t)G * 8), *h_jmin = h_cnt + G, *h_jmax = h_jmin + G;
+    if (h_jmax[G] != 0u) return bail(kBatchNotApplicable);               // a graph beyond the limits of the pass
+    // ---- the LRU replay on G keys: the same lookups, in graph order, as the general path ----------------------------------------
+    std::vector<UgsGraphDesc> desc((size_t)G);
+    std::vector<int64_t> evicted, ru, rv;
+    std::vector<std::shared_ptr<Graph>> graphs((size_t)G);
+    int64_t hits = 0, misses = 0, owned_cols = 0;
+    p->g_n.assign((size_t)G, 0); p->g_maxdeg.assign((size_t)G, 0); p->g_sbdeg.assign((size_t)G, 0.0); p->g_level.assign((size_t)G, -1);
+    touched.clear();
+    auto give_up = [&] {                                                // put the counters back: the general path repeats the lookups (same final recency order)
+        { std::lock_guard<std::mutex> lk(g_lru_mu); lru().hits -= hits; lru().misses -= misses; }
+        for (int64_t h : evicted) drop(h);
+        return bail(kBatchNotApplicable);
+    };
+    for (int64_t g = 0; g < G; ++g) {
+        UgsGraphDesc &d = desc[(size_t)g];
+        const int64_t lo = ptr[g], n = ptr[g + 1] - lo;
+        d.node_lo = lo; d.rbase = hostv[(size_t)(G + 1 + g)]; d.vbase = 0; d.viable_base = 0; d.n = 0; d.level = -1; d.n_viable = 0; d.pad = 0;
+        if (n <= 0 || n < k) continue;                                   // degenerate: m rows of -1 (never looked up: reference :132-143)
+        owned_cols += h_cnt[g];
+        const uint64_t key = (uint64_t)h_keys[g];
+        int64_t handle = 0;
+        bool hit;
+        {
+            std::lock_guard<std::mutex> lk(g_lru_mu);
+            hit = lru().get(key, handle);
+            if (hit) ++lru().hits; else ++lru().misses;
+        }
+        std::shared_ptr<Graph> gr = hit ? lookup(handle) : nullptr;
+        if (hit) ++hits; else ++misses;
+        if (!gr) {                                                       // unknown graph: sliced and preprocessed on the host, once
+            ru.clear(); rv.clear();
+            if (h_cnt[g]) for (int64_t j = h_jmin[g]; j <= (int64_t)h_jmax[g]; ++j) {
+                const int64_t u = src[j], v = dst[j];
+                if (u >= lo && u < lo + n && v >= lo && v < lo + n) { ru.push_back(u - lo); rv.push_back(v - lo); }
+            }
+            if ((int64_t)ru.size() != (int64_t)h_cnt[g]) return give_up();
+            if (int rc = make_graph(ru.data(), rv.data(), (int64_t)ru.size(), n, k, gr)) { give_up(); return rc; }
+            handle = enroll(gr);
+            int64_t ev = 0;
+            std::lock_guard<std::mutex> lk(g_lru_mu);
+            if (lru().put(key, handle, ev)) evicted.push_back(ev);
+        }
+        if (gr->n != n || gr->nnz != 2 * (int64_t)h_cnt[g]) return give_up();   // a 64-bit key collision: let the general path do what the reference does
+        Graph::DevRoots dr{};
+        if (int rc = graph_dev_roots(*gr, dc.id, ar, s, dr)) { if (rc == UGS_E_UNSUPPORTED) return give_up(); give_up(); return rc; }
+        d.n = (int32_t)n; d.level = gr->level; d.n_viable = (int32_t)gr->viable.size();
+        d.vbase = gr->level == 0 ? dr.roots_off : 0; d.viable_base = gr->level > 0 ? dr.via_off : 0;
+        p->g_n[(size_t)g] = n; p->g_maxdeg[(size_t)g] = gr->max_deg; p->g_sbdeg[(size_t)g] = gr->sb_deg; p->g_level[(size_t)g] = gr->level;
+        touched.emplace_back(key, handle);
+        graphs[(size_t)g] = gr;
+    }
+    for (int64_t h : evicted) drop(h);                                   // only evicted handles are destroyed; cached ones live on
+    evicted.clear();
+    if (debug_on()) {
+        std::lock_guard<std::mutex> lk(g_lru_mu);
+        std::fprintf(stderr, "[UGS CACHE] hits=%lld misses=%lld cache_size=%zu\n", (long long)hits, (long long)misses, lru().items.size());
+    }
+    e = hipMemcpyAsync(base + o_desc, desc.data(), desc.size() * sizeof(UgsGraphDesc), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);                    // `desc` is pageable; and later calls may come on other streams
+    if (e != hipSuccess) return bail(fail_hip(e, "plan descriptors"));
+    for (auto &gr : graphs) if (gr) p->keep.push_back(gr);
+    p->device = dc.id; p->cus = dc.cus;
+    p->G = G; p->nverts = nv; p->nnz = 2 * owned_cols;
+    p->blob = base; p->blob_bytes = off;
+    p->dev.graphs = reinterpret_cast<const UgsGraphDesc *>(base + o_desc);
+    p->dev.rowptr = reinterpret_cast<const int64_t *>(base + o_row);
+    p->dev.adj = reinterpret_cast<const int2 *>(base + o_adj);
+    p->dev.adjf = reinterpret_cast<const int2 *>(base + o_adjf);
+    p->dev.roots = ar->roots;
+    p->dev.viable = ar->via;
+    p->dev.num_graphs = G;
+    p->prow_failed = true;                       // vbase indexes the arena, not a per-plan vertex range: these plans read rows through rowptr
+    if (have_hash) {
+        p->cache_key = mum(bh.a ^ 0x6a09e667f3bcc909ull, bh.b ^ (uint64_t)k) ^ 0xd6e8feb86659fd93ull;
+        plan_cache_put(p);
+    }
+    *plan_out = p;
+    return UGS_OK;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -992,6 +1240,12 @@ int ugs_cache_clear(void) {
     return UGS_OK;
 }
 
+int ugs_batch_pass_stats(int64_t *device_plans, int64_t *general_path) {
+    if (device_plans) *device_plans = g_bp_plans.load();
+    if (general_path) *general_path = g_bp_fallbacks.load();
+    return UGS_OK;
+}
+
 int ugs_cache_stats(int64_t *size, int64_t *hits, int64_t *misses) {
     std::lock_guard<std::mutex> lk(g_lru_mu);
     Lru &c = lru();
@@ -1060,6 +1314,25 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
             std::lock_guard<std::mutex> lk(g_lru_mu);
             lru().hits -= hits;
         }
+    }
+    if (device_batch_enabled()) {                              // batches of small graphs: slicing, keys and CSR on the device
+        std::vector<std::pair<uint64_t, int64_t>> touched_d;
+        ugs_plan *dp = nullptr;
+        const int rc = device_batch_plan(src, dst, E, ptr, G, k, dc, use_index, bh, &dp, touched_d);
+        if (rc == UGS_OK) {
+            g_bp_plans.fetch_add(1);
+            if (use_index) {
+                std::lock_guard<std::mutex> lk(g_bi_mu);
+                for (auto it = g_batch_index.begin(); it != g_batch_index.end(); ++it)
+                    if (it->h == bh && it->E == E && it->G == G && it->k == k && it->dev == dc.id) { g_batch_index.erase(it); break; }
+                g_batch_index.push_front(BatchEntry{bh, E, G, k, dc.id, dp->cache_key, std::move(touched_d)});
+                while (g_batch_index.size() > g_plan_cache_cap) g_batch_index.pop_back();
+            }
+            *plan_out = dp;
+            return UGS_OK;
+        }
+        if (rc != kBatchNotApplicable) return rc;
+        g_bp_fallbacks.fetch_add(1);
     }
     std::vector<int64_t> cstart, cols_of;                      // per-graph column lists, concatenated
     Lap lap;

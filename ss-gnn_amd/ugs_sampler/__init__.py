@@ -252,6 +252,13 @@ def clear_cache():
     check(lib.ugs_cache_clear())
 
 
+def batch_pass_stats():
+    """{"device_plans": batches whose slicing / keys / CSR were built by the device pass, "general_path": batches the host path served}"""
+    a, b = C.c_int64(), C.c_int64()
+    check(lib.ugs_batch_pass_stats(C.byref(a), C.byref(b)))
+    return {"device_plans": a.value, "general_path": b.value}
+
+
 def cache_stats():
     s, h, m = C.c_int64(), C.c_int64(), C.c_int64()
     check(lib.ugs_cache_stats(C.byref(s), C.byref(h), C.byref(m)))

@@ -41,6 +41,7 @@ def _load():
         "ugs_eps_sample_batch_finish": [vp, vp, vp, vp, vp, vp, C.c_int],
         "ugs_cache_clear": [],
         "ugs_cache_stats": [i64p, i64p, i64p],
+        "ugs_batch_pass_stats": [i64p, i64p],
         "ugs_plan_create_batch": [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int, C.POINTER(vp)],
         "ugs_plan_create_handle": [C.c_int64, C.POINTER(vp)],
         "ugs_plan_release": [vp],

@@ -1,0 +1,167 @@
+"""GPU: the device batch pass (SURVEY.md 8(f) N4 for batches of small graphs, csrc/ugs_batch.hip) against the CPU oracle.
+
+The pass replaces the reference's per-graph slicing (src/ugs_sampler_batch_extension.cpp:41-75), LRU key (include/cache.hpp:81-109)
+and CSR construction (src/preproc.cpp:32-86) by one pass over edge_index + ptr on the device; the host only replays the LRU on the
+keys.  What must hold: the sampler's five output tensors equal the oracle's, call after call, with ONE shared LRU history on each
+side (keys ignore k, evictions, reuse) -- through the pass, through the general path, and when calls alternate between them."""
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _graph(rng, n, off):
+    p = rng.choice([0.03, 0.1, 0.3, 0.7])
+    e = [(u + off, v + off) for u in range(n) for v in range(u + 1, n) if rng.random() < p]
+    e = e[:450]                                                              # at most 1000 columns per graph after doubling: the pass's limit
+    if rng.random() < 0.6:
+        e = e + [(v, u) for u, v in e]                                       # both directions, like PyG
+    if rng.random() < 0.3 and n:
+        e += [(off + rng.randrange(n),) * 2 for _ in range(3)]               # self loops
+    if rng.random() < 0.2:
+        e += e[: len(e) // 5]                                                # repeated columns
+    return e[:1000]
+
+
+def _batch(rng, pool):
+    """a mini-batch: graphs drawn from `pool` (so that later batches are new combinations of known graphs) plus new ones, with
+    empty graphs, graphs smaller than k, cross-graph and out-of-range columns, and optionally interleaved columns"""
+    G = rng.randint(1, 12)
+    cols, ptr = [], [0]
+    for _ in range(G):
+        r = rng.random()
+        if r < 0.08:
+            n, e = 0, []                                                     # empty node range
+        elif r < 0.5 and pool:
+            n, e0 = pool[rng.randrange(len(pool))]
+            e = [(u + ptr[-1], v + ptr[-1]) for u, v in e0]
+        else:
+            n = rng.choice([1, 2, 3, 5, 9, 18, 39, 70, 130])
+            e = _graph(rng, n, ptr[-1])
+            pool.append((n, [(u - ptr[-1], v - ptr[-1]) for u, v in e]))
+        cols += e
+        ptr.append(ptr[-1] + n)
+    total = ptr[-1]
+    if total and rng.random() < 0.3:
+        for _ in range(4):                                                   # columns that belong to no graph
+            cols.append((rng.randrange(total), rng.randrange(total)))
+        cols += [(-1, 0), (0, total), (total + 5, 1)]
+    if rng.random() < 0.35:
+        rng.shuffle(cols)                                                    # a graph's columns need not be contiguous
+    ei = np.array(cols, dtype=np.int64).T.reshape(2, -1).copy()
+    k = rng.choice([1, 2, 3, 4, 5, 6, 8, 12])
+    return ei, np.array(ptr, dtype=np.int64), rng.choice([1, 5, 33]), k, rng.choice(["sample", "graph", "global"]), rng.choice([42, 0, -3, 99991])
+
+
+def _run(calls, env):
+    import ugs_sampler
+    prev = os.environ.get("UGS_DEVICE_BATCH")
+    ugs_sampler.clear_cache()
+    cache = oracle.Cache()
+    try:
+        for it, (ei, ptr, m, k, mode, seed) in enumerate(calls):
+            setting = env[it % len(env)]
+            if setting is None:
+                os.environ.pop("UGS_DEVICE_BATCH", None)
+            else:
+                os.environ["UGS_DEVICE_BATCH"] = setting
+            want = oracle.sample_batch(ei, ptr, m, k, mode, seed, cache)
+            got = ugs_sampler.sample_batch(torch.from_numpy(ei), torch.from_numpy(ptr), m, k, mode, seed)
+            for name, g, w in zip(("nodes", "edge_index", "edge_ptr", "sample_ptr", "edge_src"), got, want):
+                assert np.array_equal(g.numpy(), np.asarray(w)), (it, setting, name, list(np.diff(ptr)), ei.shape[1], m, k, mode, seed)
+    finally:
+        if prev is None:
+            os.environ.pop("UGS_DEVICE_BATCH", None)
+        else:
+            os.environ["UGS_DEVICE_BATCH"] = prev
+        ugs_sampler.clear_cache()
+        cache.close()
+
+
+@pytest.mark.parametrize("env", [(None,), ("0",), (None, "0", "1")])
+def test_random_minibatches_through_the_device_pass(env):
+    """default (pass on), pass off, and calls alternating between the two paths over ONE LRU history"""
+    import ugs_sampler
+    rng = random.Random(31337)
+    pool = []
+    calls = [_batch(rng, pool) for _ in range(260)]
+    before = ugs_sampler.batch_pass_stats()
+    _run(calls, env)
+    after = ugs_sampler.batch_pass_stats()
+    built = after["device_plans"] - before["device_plans"]
+    if env == ("0",):
+        assert built == 0
+    else:
+        assert built > 100, (before, after)                                  # the pass really served the calls (repeats hit the whole-batch index)
+
+
+def test_new_combinations_of_known_graphs_and_the_limits_of_the_pass():
+    """the trainer's case -- every call a new combination of graphs the LRU knows -- and batches the pass must hand to the general
+    path: a graph with more than 1000 columns, more than 2048 vertices, a non-monotone ptr"""
+    import ugs_sampler
+    import ugs_workloads as wl
+    ei, ptr = wl.tu_batch(39, 73, 32)
+    G, n_per, cols_per = 32, 39, ei.shape[1] // 32
+    rng = np.random.default_rng(5)
+    calls = [(ei, ptr, 16, 6, "sample", 42)]
+    for _ in range(12):
+        perm = rng.permutation(G)
+        blocks = [ei[:, g * cols_per:(g + 1) * cols_per] - g * n_per + i * n_per for i, g in enumerate(perm)]
+        calls.append((np.ascontiguousarray(np.concatenate(blocks, axis=1)), ptr, 16, 6, "sample", 42))
+    s0 = ugs_sampler.batch_pass_stats()
+    _run(calls, (None,))
+    s1 = ugs_sampler.batch_pass_stats()
+    assert s1["device_plans"] - s0["device_plans"] == 13 and s1["general_path"] == s0["general_path"]
+    rr = random.Random(8)
+    big_cols = np.array([(u, v) for u in range(60) for v in range(60) if u != v and rr.random() < 0.4], dtype=np.int64).T.reshape(2, -1)   # ~1400 columns
+    assert big_cols.shape[1] > 1000
+    many = np.array([(i, i + 1) for i in range(2500)], dtype=np.int64).T.reshape(2, -1)                                                   # 2501 vertices
+    overl = np.array([(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 0), (1, 4)], dtype=np.int64).T.reshape(2, -1)
+    calls = [(big_cols, np.array([0, 60], dtype=np.int64), 9, 4, "graph", 1), (many, np.array([0, 2501], dtype=np.int64), 9, 3, "global", 2),
+             (overl, np.array([2, 6, 0, 5], dtype=np.int64), 9, 3, "global", 3),
+             (np.concatenate([big_cols, ei[:, :cols_per] + 60], axis=1), np.array([0, 60, 60 + n_per], dtype=np.int64), 5, 4, "sample", 4)]
+    _run(calls, (None,))
+    s2 = ugs_sampler.batch_pass_stats()
+    assert s2["device_plans"] == s1["device_plans"] and s2["general_path"] - s1["general_path"] == 4
+
+
+def test_lru_eviction_through_the_device_pass():
+    """UGS_CACHE_SIZE=3 (fixed at first use: subprocess): multi-graph batches whose graphs evict one another, other k's in between"""
+    code = r'''
+import os, sys, random
+os.environ["UGS_CACHE_SIZE"] = "3"
+sys.path[:0] = [os.path.join(os.getcwd(), p) for p in ("tests", "oracle", "ss-gnn_amd")]
+import numpy as np, torch
+import oracle, ugs_sampler
+rng = random.Random(12)
+graphs = []
+for n in (6, 8, 10, 12, 14, 9):
+    e = [(u, v) for u in range(n) for v in range(u + 1, n) if rng.random() < 0.45]
+    graphs.append((n, e + [(v, u) for u, v in e]))
+cache = oracle.Cache(3)
+for t in range(40):
+    picks = [rng.randrange(len(graphs)) for _ in range(rng.randint(1, 4))]
+    cols, ptr = [], [0]
+    for gi in picks:
+        n, e = graphs[gi]
+        cols += [(u + ptr[-1], v + ptr[-1]) for u, v in e]
+        ptr.append(ptr[-1] + n)
+    ei = np.array(cols, dtype=np.int64).T.reshape(2, -1).copy(); ptr = np.array(ptr, dtype=np.int64)
+    k = rng.choice([3, 4, 5]); seed = rng.choice([42, 7])
+    want = oracle.sample_batch(ei, ptr, 11, k, "sample", seed, cache)
+    got = ugs_sampler.sample_batch(torch.from_numpy(ei), torch.from_numpy(ptr), 11, k, "sample", seed)
+    assert all(np.array_equal(a.numpy(), np.asarray(b)) for a, b in zip(got, want)), t
+assert ugs_sampler.batch_pass_stats()["device_plans"] >= 30
+print("OK")
+'''
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=200)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]

@@ -1,8 +1,8 @@
 """The two kinds of rank of an 8-rank strong-scaled C5 job (BASELINE config 5: 1M rows split over 8 GPUs), each emulated on ONE GPU:
 
-  destination (rank 0)  its shard's walk / scan / fill on the main stream and, beside it on a side stream, the collation of the WHOLE
-                        1M-row batch: pack of the own shard, a device copy standing in for the 7 messages arriving over xGMI, unpack
-                        of 8 messages -- double-buffered exactly like bench.py (a buffer set is free once it has been packed);
+  destination (rank 0)  its shard's walk / scan / fill, the unpack of the PREVIOUS 1M-row batch (8 messages) and the pack of its own
+                        shard, all on the main stream like bench.py's Job; on a side stream a device copy standing in for the 7
+                        messages arriving over xGMI while the next batch is sampled;
   other ranks           their shard's walk / scan / fill and the pack of their message (the send itself is a DMA).
 
 The job's step time is the slower of the two.  Run for the OLD split (equal shards, every rank's walk on 80 % of each CU: round 2)
@@ -38,34 +38,35 @@ def run(share, rows0, rank, steps=24, collate=True):
     rows_cap = max(row_off[r + 1] - row_off[r] for r in range(WORLD))
     cap = int(tot * 1.1 * rows_cap / rows) + 4096
     col = ud.Collator(total, k, "sample", node_bound, max(node_bound, m * k), ei.shape[1], cap, dev, world=WORLD, rank=rank, dst=0, row_off=row_off)
-    bufs = [(torch.empty((rows, k), dtype=torch.int64, device=dev), torch.empty((rows + 1,), dtype=torch.int64, device=dev),
-             torch.empty((2, cap), dtype=torch.int64, device=dev), torch.empty((cap,), dtype=torch.int64, device=dev)) for _ in range(2)]
+    n, p, e, s = (torch.empty((rows, k), dtype=torch.int64, device=dev), torch.empty((rows + 1,), dtype=torch.int64, device=dev),
+                  torch.empty((2, cap), dtype=torch.int64, device=dev), torch.empty((cap,), dtype=torch.int64, device=dev))
     side, main = torch.cuda.Stream(), torch.cuda.current_stream()
-    ev_fill = [torch.cuda.Event(), torch.cuda.Event()]
-    ev_packed = [torch.cuda.Event(), torch.cuda.Event()]
-    if rank == 0:                                    # realistic inbox: 8 valid messages (the other ranks' shards are about this large)
-        n, p, e, s = bufs[0]
+    ev_packed, ev_exchanged = torch.cuda.Event(), torch.cuda.Event()
+    state = {"in_flight": False}
+    if rank == 0:                                    # realistic inbox: WORLD valid messages (the other ranks' shards are about this large)
         plan.walk(m, "sample", 7, begin, rows, out=(n, p), sync=False)
         plan.fill(m, n, p, None, "sample", begin, out=(e, s))
         col.pack((n, e, p, s))
+        col.inbox.copy_(col.msg.unsqueeze(0).expand(WORLD, -1))
         torch.cuda.synchronize()
 
-    def step(i):
-        b = i & 1
-        n, p, e, s = bufs[b]
-        main.wait_event(ev_packed[b])
+    def step(i):                                     # bench.py's Job: everything on the main stream, only the exchange beside it
         plan.walk(m, "sample", 100 + i, begin, rows, out=(n, p), sync=False)
         plan.fill(m, n, p, None, "sample", begin, out=(e, s))
-        ev_fill[b].record(main)
-        if collate:
-            with torch.cuda.stream(side):
-                side.wait_event(ev_fill[b])
-                col.pack((n, e, p, s))
-                ev_packed[b].record(side)
-                if rank == 0:
-                    col.inbox[1:].copy_(col.msg.unsqueeze(0).expand(WORLD - 1, -1))   # stands in for the WORLD-1 messages arriving over xGMI
-                    col.inbox[0].copy_(col.msg)
-                    col.unpack()
+        if not collate:
+            return
+        if state["in_flight"]:
+            main.wait_event(ev_exchanged)
+            if rank == 0:
+                col.unpack()                         # the previous batch: its messages arrived while this one was sampled
+        col.pack((n, e, p, s))
+        ev_packed.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev_packed)
+            if rank == 0:
+                col.inbox[1:].copy_(col.msg.unsqueeze(0).expand(WORLD - 1, -1))   # stands in for the WORLD-1 messages arriving over xGMI
+            ev_exchanged.record(side)
+        state["in_flight"] = True
 
     for i in range(4):
         step(i)
@@ -79,7 +80,7 @@ def run(share, rows0, rank, steps=24, collate=True):
     return round(ms, 4), rows
 
 
-out = {"workload": "c5_er_1m", "world": WORLD, "global_rows": total, "cases": []}
+out = {"workload": "c5_er_1m", "world": WORLD, "global_rows": total, "stream_plan": "collation work on the main stream, exchange beside it (round 3)", "cases": []}
 equal = total // WORLD
 # old split (round 2): equal shards, every rank's walk at 80 %
 d_ms, d_rows = run(80, equal, 0)
@@ -88,7 +89,8 @@ out["old_equal_split_share80_everywhere"] = {"rank0_rows": d_rows, "rank0_ms": d
                                              "k_subgraphs_per_s": round(total / max(d_ms, o_ms) * 1e3, 1)}
 print(json.dumps(out["old_equal_split_share80_everywhere"]), flush=True)
 for share in (80, 100):
-    for rows0 in (equal, int(equal * 0.92), int(equal * 0.88), int(equal * 0.84), int(equal * 0.80)):
+    for frac in (1.0, 0.9, 0.8, 0.75, 0.7, 0.65):
+        rows0 = int(equal * frac)
         d_ms, d_rows = run(share, rows0, 0)
         d_alone, _ = run(share, rows0, 0, collate=False)
         o_ms, o_rows = run(100, rows0, 1)
@@ -98,8 +100,22 @@ for share in (80, 100):
         print(json.dumps(case), flush=True)
 best = min(out["cases"], key=lambda c: c["step_ms"])
 out["best"] = best
+# bench.py's --dst-rows auto, replayed: every round measures each kind of rank on its own, next weights = rows per millisecond
+for share in (80, 100):
+    rows0, rounds = equal, []
+    for _ in range(3):
+        d_ms, d_rows = run(share, rows0, 0, steps=8)
+        o_ms, o_rows = run(100, rows0, 1, steps=8)
+        rounds.append({"rank0_rows": d_rows, "rank0_ms": d_ms, "other_rows": o_rows, "other_ms": o_ms})
+        w0, w1 = d_rows / d_ms, o_rows / o_ms
+        rows0 = int(total * w0 / (w0 + (WORLD - 1) * w1))
+    d_ms, d_rows = run(share, rows0, 0)
+    o_ms, o_rows = run(100, rows0, 1)
+    out[f"auto_split_share{share}"] = {"calibration_rounds": rounds, "rank0_rows": d_rows, "rank0_ms": d_ms, "other_rows": o_rows, "other_ms": o_ms,
+                                       "step_ms": max(d_ms, o_ms), "k_subgraphs_per_s": round(total / max(d_ms, o_ms) * 1e3, 1)}
+    print("auto", share, json.dumps(out[f"auto_split_share{share}"]), flush=True)
 out["note"] = ("one GPU plays one rank at a time; the 7 incoming messages are a device copy; whether RCCL's receive kernels find wave slots beside "
-               "the walk is not covered (needs a multi-GPU node)")
+               "the walk is not covered (needs a multi-GPU node); bench.py uses the first two calibration rounds")
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 with open(os.path.join(ROOT, "gpurun_out", "r03_rank0_emulation.json"), "w") as f:
     json.dump(out, f, indent=1)
