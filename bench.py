@@ -716,19 +716,40 @@ def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
     for _ in range(reps):
         ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode="sample", seed=42)
     dt_host = (time.perf_counter() - t) / reps
-    # shuffled mini-batches: every call is a NEW combination of already-seen graphs (per-graph LRU hits, plan-cache miss)
+    # shuffled mini-batches: every call is a NEW combination of already-seen graphs (per-graph LRU hits, no plan to reuse): what a
+    # trainer's DataLoader produces every step.  Three disjoint sets of such batches, each batch timed once: (a) host-visible outputs,
+    # (b) device outputs, (c) host-visible with the device batch pass switched off (the general host path of rounds 1-2).
     rng = np.random.default_rng(0)
     n_per = int(ptr[1] - ptr[0])
     cols_per = ei.shape[1] // G
-    shuffled = []
-    for _ in range(min(reps, 20)):
-        perm = rng.permutation(G)
-        blocks = [ei[:, g * cols_per:(g + 1) * cols_per] - g * n_per + i * n_per for i, g in enumerate(perm)]
-        shuffled.append(torch.from_numpy(np.ascontiguousarray(np.concatenate(blocks, axis=1))))
-    t = time.perf_counter()
-    for e_s in shuffled:
-        ugs_sampler.sample_batch(e_s, ptr_t, m, k, mode="sample", seed=42)
-    dt_shuf = (time.perf_counter() - t) / len(shuffled)
+
+    def make_shuffled(count):
+        res = []
+        for _ in range(count):
+            perm = rng.permutation(G)
+            blocks = [ei[:, g * cols_per:(g + 1) * cols_per] - g * n_per + i * n_per for i, g in enumerate(perm)]
+            res.append(torch.from_numpy(np.ascontiguousarray(np.concatenate(blocks, axis=1))))
+        return res
+
+    def time_shuffled(batches, **kw):
+        tt = time.perf_counter()
+        for e_s in batches:
+            o_ = ugs_sampler.sample_batch(e_s, ptr_t, m, k, mode="sample", seed=42, **kw)
+        if kw:
+            torch.cuda.synchronize()
+        del o_
+        return (time.perf_counter() - tt) / len(batches)
+
+    nsh = min(reps, 20)
+    sets = [make_shuffled(nsh) for _ in range(3)]
+    dt_shuf = time_shuffled(sets[0])
+    dt_shuf_dev = time_shuffled(sets[1], device=dev)
+    os.environ["UGS_DEVICE_BATCH"] = "0"
+    try:
+        dt_shuf_host = time_shuffled(sets[2])
+    finally:
+        os.environ.pop("UGS_DEVICE_BATCH", None)
+    del sets
     t = time.perf_counter()
     for _ in range(reps):
         out_dev = ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode="sample", seed=42, device=dev)
@@ -740,7 +761,8 @@ def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
            "hip_graph_replay_subgraphs_per_s": round(rows / dt_graph, 1) if dt_graph else None,
            "hip_graph_replay_ms": round(dt_graph * 1e3, 4) if dt_graph else None, "hip_graph_replay": graph_stats,
            "drop_in_call_subgraphs_per_s": round(rows / dt_host, 1), "drop_in_call_ms": round(dt_host * 1e3, 4),
-           "drop_in_call_shuffled_batch_ms": round(dt_shuf * 1e3, 4), "drop_in_call_device_out_ms": round(dt_devout * 1e3, 4),
+           "drop_in_call_shuffled_batch_ms": round(dt_shuf * 1e3, 4), "drop_in_call_shuffled_batch_device_out_ms": round(dt_shuf_dev * 1e3, 4),
+           "drop_in_call_shuffled_batch_general_path_ms": round(dt_shuf_host * 1e3, 4), "drop_in_call_device_out_ms": round(dt_devout * 1e3, 4),
            "roofline": roofline}
     try:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -7,10 +7,12 @@
 //   ugs_bp_assign   one thread per column: the graph that owns it -- both endpoints inside [ptr[g], ptr[g+1]); with a
 //                   non-decreasing ptr the node ranges are disjoint, so a binary search finds the only candidate -- plus per
 //                   graph the number of its columns and the first / last column index (atomics)
-//   ugs_bp_offsets  one block: exclusive prefix of the column counts (a graph's CSR entries start at twice that)
-//   ugs_bp_build    one 256-thread block per graph: its columns in column order (ordered compaction of [first, last]), renumbered
+//                   (only for large batches; for G * E up to a few million the build kernel finds its columns itself, as the
+//                   reference's slicing does, and this launch, its memset and its atomics are saved)
+//   ugs_bp_build    one 256-thread block per graph: its columns in column order (ordered compaction of the span [first, last] of
+//                   its columns, or of all columns), renumbered
 //                   to local ids in LDS; the FNV-1a key of the reference's LRU over (n, #columns, renumbered columns) -- inherently
-//                   sequential, one lane, 2 multiplies per column; degrees, row pointer, the rank of every vertex in the reference's
+//                   sequential: 2 multiplies per column on the scalar unit; degrees, row pointer, the rank of every vertex in the reference's
 //                   ordering (ascending (degree, id): ugs_host.cpp order_by_degree) and the CSR of the symmetrised multigraph with
 //                   entries in COLUMN order (u's row then v's row per column, both entries of a self loop) written straight into
 //                   the plan's arrays: rowptr (absolute), adj = (w, rank(w)), adjf = (w, batch column)
@@ -26,89 +28,116 @@ namespace {
 constexpr int kBpBlock = 256;
 
 __global__ __launch_bounds__(256) void ugs_bp_assign(const int64_t *src, const int64_t *dst, int64_t E, const int64_t *ptr, int64_t G,
-                                                     int32_t *owner, uint32_t *cnt, uint32_t *jmin, uint32_t *jmax) {
+                                                     int32_t *owner, uint32_t *cnt, uint32_t *jminc /* 0xFFFFFFFF - first column: zero-initialised like the rest */,
+                                                     uint32_t *jmax) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= E) return;
-    const int64_t u = src[j], v = dst[j];
+    const bool in = j < E;
+    const int64_t u = in ? src[j] : -1, v = in ? dst[j] : -1;
     int32_t g = -1;
-    if (u >= ptr[0] && u < ptr[G]) {
+    if (in && u >= ptr[0] && u < ptr[G]) {
         int64_t lo = 0, hi = G;                               // last g with ptr[g] <= u (ptr is non-decreasing)
         while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (ptr[mid] <= u) lo = mid; else hi = mid; }
         // empty graphs share their ptr value with the next one: the search ends on the LAST graph starting at or below u,
         // which is the one whose range [ptr[g], ptr[g+1]) can hold u
         if (u >= ptr[lo] && u < ptr[lo + 1] && v >= ptr[lo] && v < ptr[lo + 1]) g = (int32_t)lo;
     }
-    owner[j] = g;
-    if (g >= 0) {
-        atomicAdd(&cnt[g], 1u);
-        atomicMin(&jmin[g], (uint32_t)j);
-        atomicMax(&jmax[g], (uint32_t)j);
+    if (in) owner[j] = g;
+    // per graph: column count, first and last column.  A PyG batch keeps a graph's columns together, so the lanes of a wave hold one
+    // or two graphs: one lane per DISTINCT graph of the wave does the three atomics (one per column serialised on the same words:
+    // 25 us of this 5-us kernel)
+    uint64_t todo = __ballot(g >= 0);
+    const int lane = (int)(threadIdx.x & 63);
+    while (todo) {
+        const int l0 = __ffsll((long long)todo) - 1;
+        const int32_t g0 = __shfl(g, l0, 64);
+        const uint64_t same = __ballot(g == g0);
+        if (lane == l0) {
+            const uint32_t jb = (uint32_t)(j - l0);                      // column of lane 0 of this wave
+            atomicAdd(&cnt[g0], (uint32_t)__popcll(same));
+            atomicMax(&jminc[g0], 0xFFFFFFFFu - (jb + (uint32_t)l0));     // l0 is the lowest lane holding g0
+            atomicMax(&jmax[g0], jb + (uint32_t)(63 - __clzll((long long)same)));
+        }
+        todo &= ~same;
     }
-}
-
-__global__ __launch_bounds__(1024) void ugs_bp_offsets(const uint32_t *cnt, int64_t G, uint32_t *cstart /* [G+1] */) {
-    __shared__ uint32_t sh[1024 / 64];
-    __shared__ uint32_t carry_sh;
-    if (threadIdx.x == 0) carry_sh = 0u;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int64_t base = 0; base < G; base += 1024) {
-        const int64_t g = base + threadIdx.x;
-        const uint32_t x = g < G ? cnt[g] : 0u;
-        uint32_t incl = x;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
-        if (lane == 63) sh[wv] = incl;
-        __syncthreads();
-        uint32_t woff = 0, tot = 0;
-        for (int i = 0; i < 1024 / 64; ++i) { if (i < wv) woff += sh[i]; tot += sh[i]; }
-        const uint32_t carry = carry_sh;
-        if (g < G) cstart[g] = carry + woff + incl - x;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_sh = carry + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) cstart[G] = carry_sh;
 }
 
 struct BpBuild {
     const int64_t *src, *dst, *ptr;
-    const int32_t *owner;
-    const uint32_t *cnt, *jmin, *jmax, *cstart;
+    const int32_t *owner;                 // two-kernel variant: graph of every column (ugs_bp_assign) ...
+    const uint32_t *cnt, *jminc, *jmax;   // ... and per graph its column count, 0xFFFFFFFF - first column, last column
+    int64_t G, E;
+    unsigned long long *bump;    // device counter handing out CSR space: never reset, the host knows its value at launch (bump_base);
+    unsigned long long bump_base;//   a graph's entries may lie anywhere in adj / adjf, rowptr is absolute
+    uint32_t epoch;              // written to *flag when a graph exceeds the limits (no zeroing between calls)
+    // what the host reads (pinned host memory, written by the kernel): keys[G] u64 | cnt[G] | jminc[G] | jmax[G] | flag
+    unsigned long long *h_keys;
+    uint32_t *h_cnt, *h_jminc, *h_jmax, *h_flag;
     const int64_t *rstart;       // [G] first rowptr entry of graph g (host: prefix of n_g + 1 over the non-degenerate graphs)
     int32_t k;
     int64_t *rowptr;
     int2 *adj, *adjf;
-    unsigned long long *keys;    // [G] FNV-1a key (0 for degenerate graphs: never looked up)
-    uint32_t *maxdeg;            // [G]
-    uint32_t *flag;              // set when a graph exceeds the limits of this path
 };
 
 constexpr int kBpMaxCols = UGS_BATCH_PASS_MAX_COLS, kBpMaxN = UGS_BATCH_PASS_MAX_N;
 
+template <bool FUSED>
 __global__ __launch_bounds__(kBpBlock) void ugs_bp_build(BpBuild a) {
     __shared__ uint16_t LU[kBpMaxCols], LV[kBpMaxCols];
     __shared__ int32_t LC[kBpMaxCols];                       // batch column of local column t
     __shared__ uint16_t DEG[kBpMaxN], RNK[kBpMaxN];
-    __shared__ uint32_t RP[kBpMaxN + 1];
+    __shared__ uint32_t RP[kBpMaxN + 1], CUR[kBpMaxN];
+    __shared__ unsigned long long MSK[kBpMaxN];
     __shared__ uint32_t wsum[kBpBlock / 64];
-    __shared__ uint32_t run_sh;
+    __shared__ uint32_t run_sh, cstart_sh;
     const int g = (int)blockIdx.x;
     const int64_t lo = a.ptr[g], n64 = a.ptr[g + 1] - lo;
-    if (n64 <= 0 || n64 < a.k) { if (threadIdx.x == 0) { a.keys[g] = 0ull; a.maxdeg[g] = 0u; } return; }   // degenerate: rows of -1, nothing to build
-    const uint32_t cn = a.cnt[g];
-    if (n64 > kBpMaxN || cn > (uint32_t)kBpMaxCols) { if (threadIdx.x == 0) atomicOr(a.flag, 1u); return; }
-    const int n = (int)n64;
+    if (n64 <= 0 || n64 < a.k) {                                  // degenerate: rows of -1, nothing to build, never looked up
+        if (threadIdx.x == 0) { a.h_keys[g] = 0ull; a.h_cnt[g] = 0u; a.h_jminc[g] = 0u; a.h_jmax[g] = 0u; }
+        return;
+    }
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // 1. the graph's columns in column order: ordered compaction of the span [first, last] of its columns
+    uint32_t cn = FUSED ? 0u : a.cnt[g];
+    if (n64 > kBpMaxN || cn > (uint32_t)kBpMaxCols) { if (tid == 0) *a.h_flag = a.epoch; return; }
+    const int n = (int)n64;
     if (tid == 0) run_sh = 0u;
-    for (int x = tid; x < n; x += kBpBlock) DEG[x] = 0;
     __syncthreads();
-    if (cn) {
-        const uint32_t j0 = a.jmin[g], j1 = a.jmax[g];
+    // 1. the graph's columns in column order: ordered compaction of the span [first, last] of its columns (FUSED: of all columns --
+    //    a column is the graph's iff both endpoints lie in its node range, reference src/ugs_sampler_batch_extension.cpp:52-58)
+    if constexpr (FUSED) {
+        // every wave takes a contiguous quarter of the columns: count, one block-wide exchange of the four counts, then place -- two
+        // passes over the columns (the second from cache) instead of three block barriers per chunk of 256 columns
+        const uint32_t E32 = (uint32_t)a.E, per = (((E32 + 3u) / 4u) + 63u) & ~63u;
+        const uint32_t w0 = (uint32_t)wv * per, w1 = (w0 + per < E32) ? w0 + per : E32;
+        uint32_t count = 0;
+        for (uint32_t base = w0; base < w1; base += 64) {
+            const uint32_t j = base + (uint32_t)lane;
+            bool mine = false;
+            if (j < w1) { const int64_t su = a.src[j] - lo, sv = a.dst[j] - lo; mine = (uint64_t)su < (uint64_t)n64 && (uint64_t)sv < (uint64_t)n64; }
+            count += (uint32_t)__popcll(__ballot(mine));
+        }
+        if (lane == 0) wsum[wv] = count;
+        __syncthreads();
+        uint32_t off = 0, tot = 0;
+        for (int i = 0; i < kBpBlock / 64; ++i) { if (i < wv) off += wsum[i]; tot += wsum[i]; }
+        if (tid == 0) run_sh = tot;
+        if (tot <= (uint32_t)kBpMaxCols)
+            for (uint32_t base = w0; base < w1; base += 64) {
+                const uint32_t j = base + (uint32_t)lane;
+                bool mine = false;
+                int64_t su = 0, sv = 0;
+                if (j < w1) { su = a.src[j] - lo; sv = a.dst[j] - lo; mine = (uint64_t)su < (uint64_t)n64 && (uint64_t)sv < (uint64_t)n64; }
+                const uint64_t mk = __ballot(mine);
+                if (mine) { const uint32_t t = off + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull)); LU[t] = (uint16_t)su; LV[t] = (uint16_t)sv; LC[t] = (int32_t)j; }
+                off += (uint32_t)__popcll(mk);
+            }
+        __syncthreads();
+    } else if (cn) {
+        const uint32_t j0 = 0xFFFFFFFFu - a.jminc[g], j1 = a.jmax[g];
         for (uint32_t base = j0; base <= j1; base += kBpBlock) {
             const uint32_t j = base + (uint32_t)tid;
             const bool mine = j <= j1 && a.owner[j] == g;
+            int64_t su = 0, sv = 0;
+            if (mine) { su = a.src[j] - lo; sv = a.dst[j] - lo; }
             const uint64_t mk = __ballot(mine);
             if (lane == 0) wsum[wv] = (uint32_t)__popcll(mk);
             __syncthreads();
@@ -116,39 +145,58 @@ __global__ __launch_bounds__(kBpBlock) void ugs_bp_build(BpBuild a) {
             for (int i = 0; i < wv; ++i) off += wsum[i];
             if (mine) {
                 const uint32_t t = off + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
-                LU[t] = (uint16_t)(a.src[j] - lo);
-                LV[t] = (uint16_t)(a.dst[j] - lo);
-                LC[t] = (int32_t)j;
+                LU[t] = (uint16_t)su; LV[t] = (uint16_t)sv; LC[t] = (int32_t)j;
             }
             __syncthreads();
             if (tid == 0) { uint32_t tot = 0; for (int i = 0; i < kBpBlock / 64; ++i) tot += wsum[i]; run_sh += tot; }
             __syncthreads();
         }
     }
-    // 2. the LRU key (reference include/cache.hpp:81-109; all columns: cn <= 1000 on this path): one lane, while the others count degrees
+    if constexpr (FUSED) {
+        cn = run_sh;
+        if (cn > (uint32_t)kBpMaxCols) { if (tid == 0) *a.h_flag = a.epoch; return; }
+    }
+    // the graph's place in adj / adjf, and what the host needs of it
     if (tid == 0) {
+        cstart_sh = (uint32_t)(atomicAdd(a.bump, 2ull * cn) - a.bump_base);
+        a.h_cnt[g] = cn;
+        a.h_jminc[g] = cn ? 0xFFFFFFFFu - (uint32_t)LC[0] : 0u;
+        a.h_jmax[g] = cn ? (uint32_t)LC[cn - 1] : 0u;
+    }
+    __syncthreads();
+    // 2. the LRU key (reference include/cache.hpp:81-109; all columns: cn <= 1000 on this path): one lane, while the others count degrees
+    if (wv == kBpBlock / 64 - 1) {   // the whole LAST wave (the vertex loops below start with the first) with wave-uniform values: the chain of
+                                     // 64-bit multiplies runs on the scalar unit
         const unsigned long long prime = 1099511628211ull;
         unsigned long long h = 14695981039346656037ull;
         h = (h ^ (unsigned long long)n) * prime;
         h = (h ^ (unsigned long long)cn) * prime;
-        for (uint32_t t = 0; t < cn; ++t) { h = (h ^ (unsigned long long)LU[t]) * prime; h = (h ^ (unsigned long long)LV[t]) * prime; }
-        a.keys[g] = h;
+        for (uint32_t t0 = 0; t0 < cn; t0 += 64) {       // 64 columns per LDS round trip, then lane by lane out of registers (v_readlane)
+            const uint32_t tl = t0 + (uint32_t)lane < cn ? t0 + (uint32_t)lane : 0u;
+            const int mu = (int)LU[tl], mv = (int)LV[tl];
+            const uint32_t cnt64 = cn - t0 < 64u ? cn - t0 : 64u;
+            for (uint32_t i = 0; i < cnt64; ++i) {
+                const uint32_t uu = (uint32_t)__builtin_amdgcn_readlane(mu, (int)i), vv = (uint32_t)__builtin_amdgcn_readlane(mv, (int)i);
+                h = (h ^ (unsigned long long)uu) * prime;
+                h = (h ^ (unsigned long long)vv) * prime;
+            }
+        }
+        if (lane == 0) a.h_keys[g] = h;
     }
-    // 3. degrees of the symmetrised multigraph (a self loop adds two entries to its row: reference src/preproc.cpp:47-60).  16-bit
-    //    counters packed two to a word would need word atomics; one lane per vertex counting its own row is order-free and tiny
-    for (int x = tid; x < n; x += kBpBlock) {
-        uint32_t d = 0;
-        for (uint32_t t = 0; t < cn; ++t) d += (LU[t] == x ? 1u : 0u) + (LV[t] == x ? 1u : 0u);
-        DEG[x] = (uint16_t)d;
-    }
+    // 3. degrees of the symmetrised multigraph (a self loop adds two entries to its row: reference src/preproc.cpp:47-60): one LDS
+    //    atomic per endpoint
+    for (int x = tid; x < n; x += kBpBlock) CUR[x] = 0u;
+    __syncthreads();
+    for (uint32_t t = tid; t < cn; t += kBpBlock) { atomicAdd(&CUR[LU[t]], 1u); atomicAdd(&CUR[LV[t]], 1u); }
+    __syncthreads();
+    for (int x = tid; x < n; x += kBpBlock) DEG[x] = (uint16_t)CUR[x];
     __syncthreads();
     // 4. row pointer (exclusive scan of the degrees) and the maximum degree
     {
-        uint32_t carry = 0, mx = 0;
+        uint32_t carry = 0;
         for (int base = 0; base < n; base += kBpBlock) {
             const int x = base + tid;
             const uint32_t d = x < n ? DEG[x] : 0u;
-            mx = d > mx ? d : mx;
             uint32_t incl = d;
 #pragma unroll
             for (int s = 1; s < 64; s <<= 1) { const uint32_t y = __shfl_up(incl, s, 64); if (lane >= s) incl += y; }
@@ -161,11 +209,6 @@ __global__ __launch_bounds__(kBpBlock) void ugs_bp_build(BpBuild a) {
             __syncthreads();
         }
         if (tid == 0) RP[n] = carry;
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) { const uint32_t y = __shfl_xor(mx, s, 64); mx = y > mx ? y : mx; }
-        if (lane == 0) wsum[wv] = mx;
-        __syncthreads();
-        if (tid == 0) { uint32_t m = 0; for (int i = 0; i < kBpBlock / 64; ++i) m = wsum[i] > m ? wsum[i] : m; a.maxdeg[g] = m; }
     }
     // 5. rank(x) in the reference's vertex order = ascending (CSR degree, vertex id) (src/preproc.cpp:88-140 restated: ugs_host.cpp)
     for (int x = tid; x < n; x += kBpBlock) {
@@ -175,15 +218,35 @@ __global__ __launch_bounds__(kBpBlock) void ugs_bp_build(BpBuild a) {
         RNK[x] = (uint16_t)r;
     }
     __syncthreads();
-    // 6. the plan's arrays: rows in column order (per column u's row first, then v's: both entries of a self loop land in its row)
-    const int64_t abase = 2ll * (int64_t)a.cstart[g], rbase = a.rstart[g];
+    // 6. the plan's arrays.  Rows hold their entries in COLUMN order -- per column u's row first, then v's, so both entries of a self
+    //    loop land in its row in that order (reference src/preproc.cpp:62-86).  The 2*cn endpoints e = 2t + side are placed 64 at a
+    //    time by ONE wave, in order: a running cursor per row (CUR), inside a chunk the lanes holding the same row find each other
+    //    through a 64-bit member mask per row in LDS (atomic OR, read back) and rank themselves by lane.
+    const int64_t abase = (int64_t)cstart_sh, rbase = a.rstart[g];
     for (int x = tid; x <= n; x += kBpBlock) a.rowptr[rbase + x] = abase + (int64_t)RP[x];
-    for (int x = tid; x < n; x += kBpBlock) {
-        int64_t p = abase + (int64_t)RP[x];
-        for (uint32_t t = 0; t < cn; ++t) {
+    for (int x = tid; x < n; x += kBpBlock) { CUR[x] = RP[x]; MSK[x] = 0ull; }
+    __syncthreads();
+    if (wv == 0) {
+        const uint32_t ne = 2u * cn;
+        for (uint32_t e0 = 0; e0 < ne; e0 += 64) {
+            const uint32_t e = e0 + (uint32_t)lane;
+            const bool on = e < ne;
+            const uint32_t t = on ? (e >> 1) : 0u;
             const int u = LU[t], v = LV[t];
-            if (u == x) { a.adj[p] = make_int2(v, (int)RNK[v]); a.adjf[p] = make_int2(v, LC[t]); ++p; }
-            if (v == x) { a.adj[p] = make_int2(u, (int)RNK[u]); a.adjf[p] = make_int2(u, LC[t]); ++p; }
+            const int row = (e & 1u) ? v : u, other = (e & 1u) ? u : v;       // endpoint 2t: entry v in u's row; endpoint 2t+1: entry u in v's row
+            if (on) atomicOr(&MSK[row], 1ull << lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            const unsigned long long mates = on ? MSK[row] : 0ull;
+            const uint32_t below = (uint32_t)__popcll(mates & ((1ull << lane) - 1ull));
+            const uint32_t cur = on ? CUR[row] : 0u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            if (on) {
+                const int64_t pp = abase + (int64_t)(cur + below);
+                a.adj[pp] = make_int2(other, (int)RNK[other]);
+                a.adjf[pp] = make_int2(other, LC[t]);
+                if (below == 0u) { CUR[row] = cur + (uint32_t)__popcll(mates); MSK[row] = 0ull; }   // the row's first lane of the chunk moves its cursor on
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -191,20 +254,24 @@ __global__ __launch_bounds__(kBpBlock) void ugs_bp_build(BpBuild a) {
 }  // namespace
 
 hipError_t ugs_launch_batch_pass(const int64_t *d_src, const int64_t *d_dst, int64_t E, const int64_t *d_ptr, int64_t G, int k,
-                                 int32_t *d_owner, uint32_t *d_cnt, uint32_t *d_jmin, uint32_t *d_jmax, uint32_t *d_cstart,
-                                 const int64_t *d_rstart, int64_t *d_rowptr, int2 *d_adj, int2 *d_adjf, unsigned long long *d_keys,
-                                 uint32_t *d_maxdeg, uint32_t *d_flag, hipStream_t s) {
+                                 int32_t *d_owner, uint32_t *d_cnt_jminc_jmax /* [3G], two-kernel variant only */, const int64_t *d_rstart,
+                                 int64_t *d_rowptr, int2 *d_adj, int2 *d_adjf, unsigned long long *d_bump, unsigned long long bump_base,
+                                 uint32_t epoch, void *h_back /* pinned: keys[G] u64 | cnt[G] | jminc[G] | jmax[G] | flag */, hipStream_t s) {
     if (G <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(d_cnt, 0, (size_t)G * sizeof(uint32_t), s);
-    if (e == hipSuccess) e = hipMemsetAsync(d_jmin, 0xFF, (size_t)G * sizeof(uint32_t), s);
-    if (e == hipSuccess) e = hipMemsetAsync(d_jmax, 0, (size_t)G * sizeof(uint32_t), s);
-    if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
-    if (E > 0) hipLaunchKernelGGL(ugs_bp_assign, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, d_src, d_dst, E, d_ptr, G, d_owner, d_cnt, d_jmin, d_jmax);
-    hipLaunchKernelGGL(ugs_bp_offsets, dim3(1), dim3(1024), 0, s, (const uint32_t *)d_cnt, G, d_cstart);
     BpBuild a{};
-    a.src = d_src; a.dst = d_dst; a.ptr = d_ptr; a.owner = d_owner; a.cnt = d_cnt; a.jmin = d_jmin; a.jmax = d_jmax; a.cstart = d_cstart;
-    a.rstart = d_rstart; a.k = k; a.rowptr = d_rowptr; a.adj = d_adj; a.adjf = d_adjf; a.keys = d_keys; a.maxdeg = d_maxdeg; a.flag = d_flag;
-    hipLaunchKernelGGL(ugs_bp_build, dim3((unsigned)G), dim3(kBpBlock), 0, s, a);
+    a.src = d_src; a.dst = d_dst; a.ptr = d_ptr; a.G = G; a.E = E; a.rstart = d_rstart; a.k = k; a.rowptr = d_rowptr; a.adj = d_adj; a.adjf = d_adjf;
+    a.bump = d_bump; a.bump_base = bump_base; a.epoch = epoch;
+    a.h_keys = static_cast<unsigned long long *>(h_back);
+    a.h_cnt = reinterpret_cast<uint32_t *>(a.h_keys + G); a.h_jminc = a.h_cnt + G; a.h_jmax = a.h_jminc + G; a.h_flag = a.h_jmax + G;
+    if (G * E <= UGS_BATCH_PASS_FUSED_WORK) {              // every block scans every column: no assign launch, no memset, no atomics
+        hipLaunchKernelGGL(ugs_bp_build<true>, dim3((unsigned)G), dim3(kBpBlock), 0, s, a);
+        return hipGetLastError();
+    }
+    uint32_t *d_cnt = d_cnt_jminc_jmax, *d_jminc = d_cnt + G, *d_jmax = d_jminc + G;
+    hipError_t e = hipMemsetAsync(d_cnt, 0, (size_t)(3 * G) * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ugs_bp_assign, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, d_src, d_dst, E, d_ptr, G, d_owner, d_cnt, d_jminc, d_jmax);
+    a.owner = d_owner; a.cnt = d_cnt; a.jminc = d_jminc; a.jmax = d_jmax;
+    hipLaunchKernelGGL(ugs_bp_build<false>, dim3((unsigned)G), dim3(kBpBlock), 0, s, a);
     return hipGetLastError();
 }

@@ -141,10 +141,11 @@ hipError_t ugs_launch_collate_unpack(const void *d_msgs, int world, int64_t msg_
 // device batch pass (ugs_batch.hip): slicing, LRU keys and CSR of a batch of small graphs; limits per graph of that path
 #define UGS_BATCH_PASS_MAX_COLS 1000   /* a key covers every column up to here (reference include/cache.hpp:100 samples longer graphs) */
 #define UGS_BATCH_PASS_MAX_N 2048
+#define UGS_BATCH_PASS_FUSED_WORK (4ll << 20)   /* G * E up to here: the build kernel slices the batch itself (one launch) */
 hipError_t ugs_launch_batch_pass(const int64_t *d_src, const int64_t *d_dst, int64_t E, const int64_t *d_ptr, int64_t G, int k,
-                                 int32_t *d_owner, uint32_t *d_cnt, uint32_t *d_jmin, uint32_t *d_jmax, uint32_t *d_cstart,
-                                 const int64_t *d_rstart, int64_t *d_rowptr, int2 *d_adj, int2 *d_adjf, unsigned long long *d_keys,
-                                 uint32_t *d_maxdeg, uint32_t *d_flag, hipStream_t s);
+                                 int32_t *d_owner, uint32_t *d_cnt_jminc_jmax, const int64_t *d_rstart, int64_t *d_rowptr, int2 *d_adj,
+                                 int2 *d_adjf, unsigned long long *d_bump, unsigned long long bump_base, uint32_t epoch, void *h_back,
+                                 hipStream_t s);
 hipError_t ugs_launch_scan(const uint32_t *counts, int64_t rows, int64_t *edge_ptr, int64_t *block_tmp, hipStream_t s);
 hipError_t ugs_launch_fill(const UgsFillArgs &a, int wide, int device_cus, hipStream_t s, UgsLaunchInfo *info);
 int64_t ugs_scan_tmp_words(int64_t rows);

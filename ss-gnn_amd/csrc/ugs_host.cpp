@@ -934,7 +934,11 @@ struct RootArena {
     UgsRootRec *roots = nullptr; int64_t roots_cap = 0, roots_used = 0;
     int2 *via = nullptr; int64_t via_cap = 0, via_used = 0;
     std::map<int64_t, std::vector<int64_t>> free_roots, free_via;      // exact-size reuse of released entries
-    void *pinned = nullptr; size_t pinned_bytes = 0;                    // staging of the keys coming back
+    void *pinned = nullptr; size_t pinned_bytes = 0;                    // staging: the batch going up, the keys coming back, two descriptor slots
+    hipEvent_t desc_ev[2] = {nullptr, nullptr}; int desc_slot = 0;
+    unsigned long long *d_bump = nullptr;                               // device counter handing out CSR space to the graphs of a pass (never reset)
+    unsigned long long bump_host = 0;                                   // its value before the next pass
+    uint32_t epoch = 0;                                                 // names a pass: written to the flag word by a graph beyond the limits
     std::mutex call_mu;                                                 // one device pass at a time per device (shared staging)
 };
 std::mutex g_arena_mu;
@@ -947,7 +951,8 @@ RootArena *arena_of(int dev) {
     if (it != g_arenas.end()) return it->second;
     auto *a = new RootArena();
     if (hipMalloc(reinterpret_cast<void **>(&a->roots), (size_t)kArenaRoots * sizeof(UgsRootRec)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&a->via), (size_t)kArenaVia * sizeof(int2)) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void **>(&a->via), (size_t)kArenaVia * sizeof(int2)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&a->d_bump), 256) != hipSuccess || hipMemset(a->d_bump, 0, 256) != hipSuccess) {
         (void)hipGetLastError();
         if (a->roots) (void)hipFree(a->roots);
         delete a;
@@ -1022,58 +1027,77 @@ std::atomic<int64_t> g_bp_plans{0}, g_bp_fallbacks{0};     // plans built by the
 int device_batch_plan(const int64_t *src, const int64_t *dst, int64_t E, const int64_t *ptr, int64_t G, int k, const DeviceCtx &dc,
                       bool have_hash, const Hash128 &bh, ugs_plan **plan_out, std::vector<std::pair<uint64_t, int64_t>> &touched) {
     if (G <= 0 || E <= 0 || G > ((int64_t)1 << 20) || E >= ((int64_t)1 << 24)) return kBatchNotApplicable;
-    std::vector<int64_t> hostv((size_t)(2 * G + 1));                    // ptr[G+1] | rstart[G]: one upload
+    RootArena *ar = arena_of(dc.id);
+    if (!ar) return kBatchNotApplicable;
+    std::lock_guard<std::mutex> call_lk(ar->call_mu);
+    // pinned staging, one buffer: [src E | dst E | ptr G+1 | rstart G] goes up in ONE copy, [keys G | cnt G | jminc G | jmax G | flag] comes
+    // back in one, two descriptor slots go up behind the LRU replay
+    const size_t up_words = (size_t)(2 * E + 2 * G + 1), back_bytes = (size_t)G * 20 + 8, desc_bytes = (size_t)G * sizeof(UgsGraphDesc);
+    const size_t st_back = align_up(up_words * 8), st_desc = align_up(st_back + back_bytes), st_total = align_up(st_desc + 2 * align_up(desc_bytes));
+    if (ar->pinned_bytes < st_total) {
+        if (ar->pinned) { for (auto &ev : ar->desc_ev) if (ev) (void)hipEventSynchronize(ev); (void)hipHostFree(ar->pinned); }
+        ar->pinned = nullptr; ar->pinned_bytes = 0;
+        const size_t want = std::max<size_t>(st_total * 2, 1 << 18);
+        if (hipHostMalloc(&ar->pinned, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return kBatchNotApplicable; }
+        ar->pinned_bytes = want;
+    }
+    auto *hostv = static_cast<int64_t *>(ar->pinned);                   // src | dst | ptr | rstart
+    int64_t *h_ptr = hostv + 2 * E, *h_rstart = h_ptr + (G + 1);
     int64_t rows_total = 0, nv = 0;
     for (int64_t g = 0; g < G; ++g) {
         const int64_t n = ptr[g + 1] - ptr[g];
         if (n < 0 || n > UGS_BATCH_PASS_MAX_N) return kBatchNotApplicable;      // non-monotone ptr, or a large graph
-        hostv[(size_t)(G + 1 + g)] = rows_total;
+        h_rstart[g] = rows_total;
         if (n > 0 && n >= k) { rows_total += n + 1; nv += n; }
     }
-    std::memcpy(hostv.data(), ptr, (size_t)(G + 1) * sizeof(int64_t));
-    RootArena *ar = arena_of(dc.id);
-    if (!ar) return kBatchNotApplicable;
-    std::lock_guard<std::mutex> call_lk(ar->call_mu);
+    std::memcpy(hostv, src, (size_t)E * 8);
+    std::memcpy(hostv + E, dst, (size_t)E * 8);
+    std::memcpy(h_ptr, ptr, (size_t)(G + 1) * sizeof(int64_t));
     // ---- one device allocation: the plan's arrays, then the pass's inputs and scratch -------------------------------------------
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + std::max<size_t>(bytes, 8)); return o; };
-    const size_t o_desc = take((size_t)G * sizeof(UgsGraphDesc)), o_row = take((size_t)rows_total * sizeof(int64_t));
+    const size_t o_desc = take(desc_bytes), o_row = take((size_t)rows_total * sizeof(int64_t));
     const size_t o_adj = take((size_t)2 * E * sizeof(int2)), o_adjf = take((size_t)2 * E * sizeof(int2));
-    const size_t o_src = take((size_t)E * 8), o_dst = take((size_t)E * 8), o_ptr = take((size_t)(2 * G + 1) * 8);
-    const size_t o_owner = take((size_t)E * 4), o_cstart = take((size_t)(G + 1) * 4), o_maxdeg = take((size_t)G * 4);
-    // what comes back, contiguous: keys[G] u64 | cnt[G] | jmin[G] | jmax[G] | flag
-    const size_t back_bytes = (size_t)G * 20 + 8;
-    const size_t o_back = take(back_bytes);
+    const bool fused = G * E <= UGS_BATCH_PASS_FUSED_WORK;
+    const size_t o_up = take(up_words * 8), o_owner = take(fused ? 8 : (size_t)E * 4), o_cnt = take(fused ? 8 : (size_t)G * 12);
     auto *p = new ugs_plan();
     if (int rc = pool_get(off, dc.id, p->blob_buf)) { delete p; return rc; }
     char *base = static_cast<char *>(p->blob_buf.p);
     auto bail = [&](int rc) { pool_put(p->blob_buf); delete p; return rc; };
-    if (ar->pinned_bytes < back_bytes) {
-        if (ar->pinned) (void)hipHostFree(ar->pinned);
-        ar->pinned = nullptr; ar->pinned_bytes = 0;
-        const size_t want = std::max<size_t>(back_bytes * 2, 1 << 16);
-        if (hipHostMalloc(&ar->pinned, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return bail(kBatchNotApplicable); }
-        ar->pinned_bytes = want;
-    }
     hipStream_t s = dc.stream;
-    auto *d_src = reinterpret_cast<int64_t *>(base + o_src), *d_dst = reinterpret_cast<int64_t *>(base + o_dst), *d_ptr = reinterpret_cast<int64_t *>(base + o_ptr);
-    auto *d_keys = reinterpret_cast<unsigned long long *>(base + o_back);
-    auto *d_cnt = reinterpret_cast<uint32_t *>(base + o_back + (size_t)G * 8), *d_jmin = d_cnt + G, *d_jmax = d_jmin + G, *d_flag = d_jmax + G;
-    hipError_t e = hipMemcpyAsync(d_src, src, (size_t)E * 8, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_dst, dst, (size_t)E * 8, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_ptr, hostv.data(), hostv.size() * 8, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = ugs_launch_batch_pass(d_src, d_dst, E, d_ptr, G, k, reinterpret_cast<int32_t *>(base + o_owner), d_cnt, d_jmin, d_jmax,
-                                                   reinterpret_cast<uint32_t *>(base + o_cstart), d_ptr + (G + 1), reinterpret_cast<int64_t *>(base + o_row),
-                                                   reinterpret_cast<int2 *>(base + o_adj), reinterpret_cast<int2 *>(base + o_adjf), d_keys,
-                                                   reinterpret_cast<uint32_t *>(base + o_maxdeg), d_flag, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(ar->pinned, base + o_back, back_bytes, hipMemcpyDeviceToHost, s);
+    Lap lap;
+    auto *d_src = reinterpret_cast<int64_t *>(base + o_up), *d_dst = d_src + E, *d_ptr = d_dst + E;
+    // what comes back is written by the kernel straight into the pinned staging (keys[G] u64 | cnt[G] | jminc[G] | jmax[G] | flag): no
+    // copy command behind the kernel, the host waits for the stream only
+    char *h_back = static_cast<char *>(ar->pinned) + st_back;
+    const uint32_t epoch = ++ar->epoch ? ar->epoch : ++ar->epoch;       // never 0
+    *reinterpret_cast<volatile uint32_t *>(h_back + (size_t)G * 20) = 0u;
+    hipError_t e = hipMemcpyAsync(d_src, hostv, up_words * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = ugs_launch_batch_pass(d_src, d_dst, E, d_ptr, G, k, reinterpret_cast<int32_t *>(base + o_owner), reinterpret_cast<uint32_t *>(base + o_cnt),
+                                                   d_ptr + (G + 1), reinterpret_cast<int64_t *>(base + o_row), reinterpret_cast<int2 *>(base + o_adj),
+                                                   reinterpret_cast<int2 *>(base + o_adjf), ar->d_bump, ar->bump_host, epoch, h_back, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return bail(fail_hip(e, "device batch pass"));
-    const auto *h_keys = static_cast<const unsigned long long *>(ar->pinned);
-    const auto *h_cnt = reinterpret_cast<const uint32_t *>(static_cast<const char *>(ar->pinned) + (size_t)G * 8), *h_jmin = h_cnt + G, *h_jmax = h_jmin + G;
-    if (h_jmax[G] != 0u) return bail(kBatchNotApplicable);               // a graph beyond the limits of the pass
+    if (e != hipSuccess) {       // the counter's value is unknown now: start again from zero
+        (void)hipMemset(ar->d_bump, 0, 8); ar->bump_host = 0;
+        return bail(fail_hip(e, "device batch pass"));
+    }
+    const double t_pass = lap();
+    const auto *h_keys = reinterpret_cast<const unsigned long long *>(h_back);
+    const auto *h_cnt = reinterpret_cast<const uint32_t *>(h_back + (size_t)G * 8), *h_jminc = h_cnt + G, *h_jmax = h_jminc + G;
+    {   // the counter moved by twice the columns of the graphs that got as far as their allocation: re-derive it from what came back
+        unsigned long long used = 0;
+        for (int64_t g = 0; g < G; ++g) used += 2ull * h_cnt[g];
+        if (h_jmax[G] == epoch) {                                        // a graph beyond the limits of the pass: which blocks allocated is not known
+            (void)hipMemset(ar->d_bump, 0, 8); ar->bump_host = 0;
+            return bail(kBatchNotApplicable);
+        }
+        ar->bump_host += used;
+    }
     // ---- the LRU replay on G keys: the same lookups, in graph order, as the general path ----------------------------------------
-    std::vector<UgsGraphDesc> desc((size_t)G);
+    const int slot = ar->desc_slot ^= 1;                                 // the copy of the call before last on this device is long over; wait if not
+    if (!ar->desc_ev[slot]) { if (hipEventCreateWithFlags(&ar->desc_ev[slot], hipEventDisableTiming) != hipSuccess) return bail(fail(UGS_E_HIP, "hipEventCreate")); }
+    else (void)hipEventSynchronize(ar->desc_ev[slot]);
+    UgsGraphDesc *desc = reinterpret_cast<UgsGraphDesc *>(static_cast<char *>(ar->pinned) + st_desc + (size_t)slot * align_up(desc_bytes));
     std::vector<int64_t> evicted, ru, rv;
     std::vector<std::shared_ptr<Graph>> graphs((size_t)G);
     int64_t hits = 0, misses = 0, owned_cols = 0;
@@ -1087,7 +1111,7 @@ int device_batch_plan(const int64_t *src, const int64_t *dst, int64_t E, const i
     for (int64_t g = 0; g < G; ++g) {
         UgsGraphDesc &d = desc[(size_t)g];
         const int64_t lo = ptr[g], n = ptr[g + 1] - lo;
-        d.node_lo = lo; d.rbase = hostv[(size_t)(G + 1 + g)]; d.vbase = 0; d.viable_base = 0; d.n = 0; d.level = -1; d.n_viable = 0; d.pad = 0;
+        d.node_lo = lo; d.rbase = h_rstart[g]; d.vbase = 0; d.viable_base = 0; d.n = 0; d.level = -1; d.n_viable = 0; d.pad = 0;
         if (n <= 0 || n < k) continue;                                   // degenerate: m rows of -1 (never looked up: reference :132-143)
         owned_cols += h_cnt[g];
         const uint64_t key = (uint64_t)h_keys[g];
@@ -1102,7 +1126,7 @@ int device_batch_plan(const int64_t *src, const int64_t *dst, int64_t E, const i
         if (hit) ++hits; else ++misses;
         if (!gr) {                                                       // unknown graph: sliced and preprocessed on the host, once
             ru.clear(); rv.clear();
-            if (h_cnt[g]) for (int64_t j = h_jmin[g]; j <= (int64_t)h_jmax[g]; ++j) {
+            if (h_cnt[g]) for (int64_t j = (int64_t)(0xFFFFFFFFu - h_jminc[g]); j <= (int64_t)h_jmax[g]; ++j) {
                 const int64_t u = src[j], v = dst[j];
                 if (u >= lo && u < lo + n && v >= lo && v < lo + n) { ru.push_back(u - lo); rv.push_back(v - lo); }
             }
@@ -1128,9 +1152,14 @@ int device_batch_plan(const int64_t *src, const int64_t *dst, int64_t E, const i
         std::lock_guard<std::mutex> lk(g_lru_mu);
         std::fprintf(stderr, "[UGS CACHE] hits=%lld misses=%lld cache_size=%zu\n", (long long)hits, (long long)misses, lru().items.size());
     }
-    e = hipMemcpyAsync(base + o_desc, desc.data(), desc.size() * sizeof(UgsGraphDesc), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);                    // `desc` is pageable; and later calls may come on other streams
+    const double t_lru = lap();
+    e = hipMemcpyAsync(base + o_desc, desc, desc_bytes, hipMemcpyHostToDevice, s);      // pinned source: truly asynchronous; the plan's first
+    if (e == hipSuccess) e = hipEventRecord(ar->desc_ev[slot], s);                        // walk is ordered behind it on the plan (plan_enter)
     if (e != hipSuccess) return bail(fail_hip(e, "plan descriptors"));
+    if (int rc = plan_leave(p, s)) return bail(rc);                      // a first call on another stream waits for the descriptors (plan_enter)
+    if (std::getenv("UGS_BP_TRACE"))
+        std::fprintf(stderr, "[UGS BATCH PASS] G=%lld E=%lld: upload + pass + keys back %.1f us, LRU replay + arena %.1f us, descriptors %.1f us\n",
+                     (long long)G, (long long)E, t_pass * 1e6, t_lru * 1e6, lap() * 1e6);
     for (auto &gr : graphs) if (gr) p->keep.push_back(gr);
     p->device = dc.id; p->cus = dc.cus;
     p->G = G; p->nverts = nv; p->nnz = 2 * owned_cols;
