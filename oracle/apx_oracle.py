@@ -216,3 +216,98 @@ def chi_square_p(counts, law):
         exp.append(pe)
     chi2 = sum((o - e) ** 2 / e for o, e in zip(obs, exp))
     return float(stats.chi2.sf(chi2, len(obs) - 1)), chi2, len(obs) - 1
+
+
+def law_k(adj, pos, est, epsilon, k, mc=200_000, seed=12345):
+    """{(v, s1, ..., s_{k-1}): probability}, total acceptance per trial -- the law of the ORDERED graphlet for any k >= 3
+    (used for k = 4; law_k3 is the fully enumerated special case and the check of this function).
+
+    Root and growth factors are enumerated exactly like law_k3: at growth step i the i cut estimates are independent binomial
+    counts, and `from` is S[j] with probability E[c_j / sum c] (reference :271-300).  The acceptance factor
+    E[min(1, K / (est(v) p_hat))] (reference :318-382, :440-447) sums p_hat over the (k-1)! orders of the non-root vertices, each
+    order a product of k-1 ratios links_i / (sum of i+1 fresh cut estimates): for k = 4 that is 36 independent binomials per
+    graphlet, whose joint support is too large to enumerate -- the expectation is taken over `mc` joint draws of those binomials
+    from a fixed generator (relative error of the factor ~ 1/sqrt(mc), far below what a chi-square test on thousands of rows
+    resolves).  The factor depends only on (v, set of the others), so it is computed once per vertex set."""
+    import itertools
+    C1, C2 = 2, 2
+    n = len(adj)
+    deg = [len(a) for a in adj]
+    beta = epsilon / 2.0
+    alpha = beta ** (1.0 / (k - 1)) / (6.0 * k ** 3)
+    gamma = epsilon * 3.0 ** (-k) * float(k) ** (-C2)
+    rho = gamma
+    hg, lg = cut_params(k, alpha, beta, gamma / k ** 4)
+    hp, lp = cut_params(k, alpha, beta / k ** 6, rho / (k * k))
+    Z = sum(est)
+    K = (beta / Z) * float(k) ** (-C1)
+    later = lambda v, w: pos[v] < pos[w]
+    rng = np.random.default_rng(seed)
+
+    def frac(v, u, U):
+        return sum(1 for w in adj[u] if later(v, w) and w not in U) / deg[u] if deg[u] else 0.0
+
+    def step_probs(v, S):
+        """{w: P(next vertex = w | grown so far = S)} (missing mass = the trial fails here)"""
+        dists = [_cut_dist(deg[u], frac(v, u, set(S)), hg, lg) for u in S]
+        pick = [0.0] * len(S)
+        for combo in itertools.product(*dists):
+            tot = sum(c for c, _ in combo)
+            if tot <= 0:
+                continue
+            p = 1.0
+            for _, q in combo:
+                p *= q
+            for j, (c, _) in enumerate(combo):
+                pick[j] += p * c / tot
+        out = {}
+        for j, u in enumerate(S):
+            ok = [w for w in adj[u] if later(v, w) and w not in S]
+            for w in ok:
+                out[w] = out.get(w, 0.0) + pick[j] / len(ok)
+        return out
+
+    def draw_cut(u, v, U, size):
+        f = frac(v, u, U)
+        hits = rng.binomial(hp, f, size=size) if 0.0 < f < 1.0 else np.full(size, hp if f >= 1.0 else 0)
+        return np.where(hits >= lp, deg[u] * hits / hp, 0.0)
+
+    acc_cache = {}
+
+    def accept(v, rest):
+        key = (v, frozenset(rest))
+        if key in acc_cache:
+            return acc_cache[key]
+        p_hat = np.zeros(mc)
+        for perm in itertools.permutations(sorted(rest)):
+            seq = (v,) + perm
+            p = np.ones(mc)
+            for i in range(k - 1):
+                Si = seq[: i + 1]
+                links = sum(1 for u in Si if seq[i + 1] in adj[u])
+                ci = np.zeros(mc)
+                for u in Si:
+                    ci += draw_cut(u, v, set(Si), mc)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    p = np.where((ci > 0) & (p > 0), p * links / np.where(ci > 0, ci, 1.0), 0.0)
+            p_hat += p
+        with np.errstate(divide="ignore"):
+            a = np.where(p_hat > 0, np.minimum(1.0, K / (est[v] * np.where(p_hat > 0, p_hat, 1.0))), 0.0)
+        acc_cache[key] = float(a.mean())
+        return acc_cache[key]
+
+    law = {}
+
+    def extend(v, S, p):
+        if len(S) == k:
+            law[tuple(S)] = (est[v] / Z) * p * accept(v, S[1:])
+            return
+        for w, q in sorted(step_probs(v, S).items()):
+            if q > 0.0:
+                extend(v, S + [w], p * q)
+
+    for v in range(n):
+        if est[v] > 0.0:
+            extend(v, [v], 1.0)
+    s = sum(law.values())
+    return {key: val / s for key, val in law.items()}, s

@@ -928,7 +928,7 @@ int plan_leave(ugs_plan *plan, hipStream_t s) {
 // UGS_BATCH_PASS_MAX_COLS columns -- up to there the key covers a graph's whole content, so a cached graph with the same key
 // has exactly the CSR the pass has just built (beyond, the reference's key samples the columns and the general path below
 // reproduces what it then does: it samples from the CACHED graph).  Everything else takes the general path.
-// UGS_DEVICE_BATCH=0 switches the pass off, =1 is the default.
+// UGS_DEVICE_BATCH=0 switches the pass off, =1 forces it wherever it applies (see device_batch_mode).
 // ---------------------------------------------------------------------------------------------------------------
 struct RootArena {
     UgsRootRec *roots = nullptr; int64_t roots_cap = 0, roots_used = 0;
@@ -1014,9 +1014,16 @@ int graph_dev_roots(Graph &g, int dev, RootArena *ar, hipStream_t s, Graph::DevR
     return UGS_OK;
 }
 
-bool device_batch_enabled() {
+// UGS_DEVICE_BATCH: 0 = never, 1 = whenever applicable, unset = whenever applicable and the batch has at least
+// kBatchPassMinCols columns.  Below that the chain upload -> kernel -> keys back (~30 us of latencies) costs more than the host's
+// own pass over a few hundred columns (measured, C2 / C4 shapes: 0.15 against 0.13 ms per call); above it the pass wins (C3 shape,
+// 4672 columns: 0.276 against 0.295 ms host-visible, 0.189 against 0.197 ms with device outputs).
+constexpr int64_t kBatchPassMinCols = 2048;
+int device_batch_mode() {
     const char *e = std::getenv("UGS_DEVICE_BATCH");
-    return !(e && e[0] == '0');
+    if (e && e[0] == '0') return 0;
+    if (e && e[0] == '1') return 1;
+    return 2;
 }
 
 constexpr int kBatchNotApplicable = 1;      // positive: not an error code of the C ABI
@@ -1344,7 +1351,8 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
             lru().hits -= hits;
         }
     }
-    if (device_batch_enabled()) {                              // batches of small graphs: slicing, keys and CSR on the device
+    const int bp_mode = device_batch_mode();
+    if (bp_mode == 1 || (bp_mode == 2 && E >= kBatchPassMinCols)) {   // batches of small graphs: slicing, keys and CSR on the device
         std::vector<std::pair<uint64_t, int64_t>> touched_d;
         ugs_plan *dp = nullptr;
         const int rc = device_batch_plan(src, dst, E, ptr, G, k, dc, use_index, bh, &dp, touched_d);

@@ -397,7 +397,7 @@ __device__ __forceinline__ uint32_t select_in_order(const Work<SP> &ws, const Gr
 //   5. every element reads its bucket's (tiny) list and counts the members above it -> rank = start + count; scatter.
 // No loop over rounds: nine LDS round trips whatever the bucket sizes (a bucket of more than UNR members takes a short
 // extra loop).
-template <int GS, int NJ>
+template <int GS, int NJ, bool POS_IN_NEW = false>
 __device__ __forceinline__ void stage_mat(const Work<LdsSpace> &ws, const Grp<GS> &g, const uint16_t *OLD, uint16_t *NEW,
                                           uint32_t n_old, uint32_t B, uint32_t M, uint32_t S) {
     constexpr int UNR = NJ <= 5 ? 6 : 4;
@@ -447,7 +447,9 @@ __device__ __forceinline__ void stage_mat(const Work<LdsSpace> &ws, const Grp<GS
         run += gs[j];
     }
     LdsSpace::sync();
-    uint16_t *POS = reinterpret_cast<uint16_t *>(ws.TBL + ((B + 3u) & ~3u));
+    // the per-bucket position lists: behind the table, or -- in a tier whose table is only as large as its largest stage -- in the
+    // stage's own order array, which is written only after the last read of the lists (the barrier in front of the scatter)
+    uint16_t *POS = POS_IN_NEW ? NEW : reinterpret_cast<uint16_t *>(ws.TBL + ((B + 3u) & ~3u));
     uint32_t st[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) st[j] = atomicAdd(&ws.TBL[bk[j]], valid[j] ? 0x10000u : 0u);
@@ -610,12 +612,16 @@ __device__ __forceinline__ void stage_mat_reg2(const Work<LdsSpace> &ws, const G
 // the table atomics (all of them on one address would serialise).  So only the lane holding candidate L-1 enters elements past
 // L; their bucket's first position is the highest of all, it is laid out FIRST and merely shifts every real rank by its size:
 // the search looks for rsel + that size, and no later test asks whether an element is valid.
-template <int GS, int NJ>
+// PASSES > 1 (a tier whose bucket table holds only 1/PASSES of the final stage's buckets): the table phases run once per bucket range
+// -- an element takes part in the pass that owns its bucket -- and the leaders' sizes are collected over the passes; everything
+// after the table (scan, search, the one bucket's members) is unchanged.
+template <int GS, int NJ, int PASSES = 1>
 __device__ __forceinline__ Pick stage_final(const Work<LdsSpace> &ws, const Grp<GS> &g, const uint16_t *OLD, uint32_t n_old,
                                             uint32_t L, uint32_t B, uint32_t M, uint32_t S, uint32_t rsel) {
     const uint32_t t0 = (uint32_t)g.lane * NJ;
     uint32_t pos[NJ], bk[NJ];                                                   // position in D; the key is only needed for the bucket
-    {
+    const uint32_t H = PASSES > 1 ? (B + (uint32_t)PASSES) / (uint32_t)PASSES : B + 1u;   // buckets (slots 0 .. B) per pass
+    if constexpr (PASSES == 1) {
         uint4 *T4 = reinterpret_cast<uint4 *>(ws.TBL);
         const uint32_t n4 = (B + 4u) >> 2;                                      // slots 0 .. B
         for (uint32_t i = g.lane; i < n4; i += GS) T4[i] = make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu);
@@ -638,20 +644,49 @@ __device__ __forceinline__ Pick stage_final(const Work<LdsSpace> &ws, const Grp<
             const uint32_t m = mod_stage(key[j], B, M, S);
             bk[j] = t0 + j < L ? m : B;
         }
-        if (t0 < L) {
+        if constexpr (PASSES == 1) {
+            if (t0 < L) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) atomicMin(&ws.TBL[bk[j]], t0 + j);
+                for (int j = 0; j < NJ; ++j) atomicMin(&ws.TBL[bk[j]], t0 + j);
+            }
         }
     }
-    LdsSpace::sync();
-    if (t0 < L) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) atomicAdd(&ws.TBL[bk[j]], 0x10000u);
-    }
-    LdsSpace::sync();
     uint32_t gs[NJ], mine_total = 0u;
+    if constexpr (PASSES == 1) {
+        LdsSpace::sync();
+        if (t0 < L) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) gs[j] = ws.TBL[bk[j]];                 // (size << 16) | first position
+            for (int j = 0; j < NJ; ++j) atomicAdd(&ws.TBL[bk[j]], 0x10000u);
+        }
+        LdsSpace::sync();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) gs[j] = ws.TBL[bk[j]];                 // (size << 16) | first position
+    } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) gs[j] = 0xFFFFFFFFu;                   // first position 0xFFFF: no element's own
+        for (uint32_t ps = 0; ps < (uint32_t)PASSES; ++ps) {
+            const uint32_t b0 = ps * H;
+            {
+                uint4 *T4 = reinterpret_cast<uint4 *>(ws.TBL);
+                const uint32_t n4 = (H + 3u) >> 2;
+                for (uint32_t i = g.lane; i < n4; i += GS) T4[i] = make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu);
+            }
+            LdsSpace::sync();
+            if (t0 < L) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) if (bk[j] - b0 < H) atomicMin(&ws.TBL[bk[j] - b0], t0 + j);
+            }
+            LdsSpace::sync();
+            if (t0 < L) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) if (bk[j] - b0 < H) atomicAdd(&ws.TBL[bk[j] - b0], 0x10000u);
+            }
+            LdsSpace::sync();
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { const uint32_t lb = bk[j] - b0; const uint32_t v = ws.TBL[lb < H ? lb : 0u]; gs[j] = lb < H ? v : gs[j]; }
+            LdsSpace::sync();
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         gs[j] = (gs[j] & 0xFFFFu) == t0 + j ? (gs[j] >> 16) : 0u;       // bucket leaders carry the size
@@ -702,6 +737,11 @@ __device__ __forceinline__ Pick stage_final(const Work<LdsSpace> &ws, const Grp<
 // carries the variants its candidate range (B[stage-1], min(B[stage], CAP)] can need.
 constexpr int nj_of(int per) { return per <= 1 ? 1 : per <= 3 ? 3 : per <= 5 ? 5 : per <= 7 ? 7 : per <= 9 ? 9 : per <= 13 ? 13 : per <= 17 ? 17 : 33; }
 constexpr int nst_of(int cap) { return cap <= 64 ? 3 : (cap <= 512 ? 5 : (cap <= 1024 ? 6 : 7)); }       // stages that are ever materialised
+// Bucket-table words of a tier.  Normally the smallest chain value >= CAP (the final stage's buckets in one piece).  The 704-candidate
+// tier keeps only HALF of its final stage's 1109 + 1 slots (stage_final runs two passes there) and lets the 541-bucket stage put its
+// position lists into its own order array: 11.6 KB per walk instead of 19.4 KB, 12 walks per CU instead of 8.
+constexpr int tier_index(int cap) { return cap <= 64 ? 0 : (cap <= 512 ? 1 : (cap <= 704 ? 2 : (cap <= 1024 ? 3 : 4))); }
+constexpr int tbl_words(int cap) { constexpr int w[5] = {127, 541, 555, 1109, 2357}; return (w[tier_index(cap)] + 3) & ~3; }
 
 template <int STAGE> struct ChainAt {
     static constexpr uint32_t B = kChainHost[STAGE], M = cmagic(kChainHost[STAGE]), S = (uint32_t)clog2(kChainHost[STAGE]) - 1u;
@@ -717,11 +757,13 @@ __device__ __forceinline__ void mat_at(const Work<LdsSpace> &ws, const Grp<GS> &
     uint16_t *NEW = ws.ORD + C::O;
     constexpr int per = (int)((C::B + GS - 1) / GS);                          // these stages are full: L == B
     STAMP_SUB_BEGIN();
+    // position lists behind the table only where the tier's table has the room (see tbl_words)
+    constexpr bool POS_IN_NEW = (int)(((C::B + 3u) & ~3u) + (C::B + 1u) / 2u) > tbl_words(MAXPER * GS);
     if constexpr (GS == 64 && per <= 1) stage_mat_reg(ws, g, OLD, NEW, C::NOLD, C::B, C::M, C::S);
     // (for 65..128 elements the register ranking, 203 VALU instructions, still beats the bucket-table variant with 2 elements per
     // lane, 169 instructions but nine LDS round trips: 6.81 against 6.95 ms per 1M walks)
     else if constexpr (GS == 64 && per <= 2) stage_mat_reg2(ws, g, OLD, NEW, C::NOLD, C::B, C::M, C::S);
-    else stage_mat<GS, nj_of(per)>(ws, g, OLD, NEW, C::NOLD, C::B, C::M, C::S);
+    else stage_mat<GS, nj_of(per), POS_IN_NEW>(ws, g, OLD, NEW, C::NOLD, C::B, C::M, C::S);
     STAMP_SUB_END(per <= 1 ? 10 : (per <= 2 ? 11 : 12));
 }
 
@@ -742,7 +784,9 @@ __device__ __forceinline__ Pick final_at(const Work<LdsSpace> &ws, const Grp<GS>
     // register-ranked final (78 VALU instructions against 59 + 7 LDS operations for the table variant: the shorter dependency
     // chain wins); from 65 on the bucket-table variant with exactly ceil(c/64) elements per lane -- for 65..128 candidates it
     // takes 93 VALU instructions where ranking two elements per lane in registers took 207 (7.16 -> 7.01 ms per 1M walks).
-#define UGS_FINAL_LDS(LO, HI, NJ) UGS_FINAL_CASE(LO, HI, (stage_final<GS, NJ>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
+    constexpr int PASSES = (int)C::B + 1 > tbl_words((int)CAP) ? 2 : 1;          // the table holds the stage's slots 0 .. B in one piece, or half of them
+    static_assert(((int)C::B + PASSES) / PASSES <= tbl_words((int)CAP), "a pass of the final stage must fit the tier's bucket table");
+#define UGS_FINAL_LDS(LO, HI, NJ) UGS_FINAL_CASE(LO, HI, (stage_final<GS, NJ, PASSES>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
     if constexpr (GS == 64) {
         UGS_FINAL_CASE(1, 1, stage_final_reg(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel))
         UGS_FINAL_LDS(2, 2, 2) UGS_FINAL_LDS(3, 3, 3) UGS_FINAL_LDS(4, 4, 4) UGS_FINAL_LDS(5, 5, 5) UGS_FINAL_LDS(6, 6, 6) UGS_FINAL_LDS(7, 7, 7)
@@ -1162,12 +1206,12 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
 template <int CAP> struct TierCfg {
     static constexpr int NSTAGE = nst_of(CAP);                                     // stages that are ever materialised
     static constexpr int ORDW = (int)(((ord_words_before(NSTAGE) + 1u) / 2u + 3u) & ~3u);   // 16-bit positions: 52 / 248 / 520 / 1072 words
-    static constexpr int BCAP = CAP <= 64 ? 127 : (CAP <= 512 ? 541 : (CAP <= 1024 ? 1109 : 2357));   // smallest chain value >= CAP
-    static constexpr int BCAP_A = (BCAP + 3) & ~3;
-    static constexpr int HS = CAP <= 64 ? 128 : (CAP <= 512 ? 512 : (CAP <= 1024 ? 2048 : 4096));
-    static constexpr int HLIMIT = CAP <= 512 && CAP > 64 ? HS / 8 * 7 : HS / 4 * 3;   // max distinct vertices a walk may have seen
+    static constexpr int TI = tier_index(CAP);
+    static constexpr int BCAP_A = tbl_words(CAP);                                   // bucket-table words (see tbl_words)
+    static constexpr int HS = TI == 0 ? 128 : (TI == 1 ? 512 : (TI == 2 ? 1024 : (TI == 3 ? 2048 : 4096)));
+    static constexpr int HLIMIT = (TI == 1 || TI == 2) ? HS / 8 * 7 : HS / 4 * 3;   // max distinct vertices a walk may have seen
     static_assert(CAP <= 64 || BCAP_A * 4 >= 127 * 16, "mates2_by_table keeps 16 bytes per bucket of the 127-bucket stage in TBL");
-    static_assert(HLIMIT == UGS_TIER_HASH_LIMIT[CAP <= 64 ? 0 : (CAP <= 512 ? 1 : (CAP <= 1024 ? 2 : 3))], "host tier logic (choose_tier) relies on this limit");
+    static_assert(HLIMIT == UGS_TIER_HASH_LIMIT[TI] && CAP == UGS_TIER_CAP[TI], "host tier logic (choose_tier) relies on these limits");
     static constexpr int ELW = CAP > 64 ? 4 * UGS_STAGE_ENTRIES : 0;             // staged hits (one-walk-per-wave tiers)
     static constexpr int WORDS = CAP /*D*/ + ORDW + BCAP_A /*TBL*/ + HS /*HK*/ + UGS_KMAX /*SV*/ + ELW;
 };
@@ -1178,7 +1222,7 @@ template <int CAP> struct TierCfg {
 // (10.63 vs 10.43 ms: a launch ended with the waves of the fuller SIMDs); with the shared work counter the extra waves are
 // pure throughput: 8.81 -> 8.51 ms.  Spilling further to reach more waves costs more than it brings (30 % in an early build).
 template <int GS, int CAP, int BLOCK, bool PAD>
-__global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP <= 64 || CAP == 1024 ? 2 : 1)) void ugs_walk_lds(UgsWalkArgs a) {
+__global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP == 704 ? 3 : (CAP <= 64 || CAP == 1024 ? 2 : 1))) void ugs_walk_lds(UgsWalkArgs a) {
     using Cfg = TierCfg<CAP>;
     constexpr int GROUPS = BLOCK / GS;
     __shared__ __attribute__((aligned(16))) uint32_t lds[GROUPS * Cfg::WORDS];
@@ -1611,6 +1655,8 @@ hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, int share_pe
     // resident one-wave blocks per CU: LDS is granted in 1280-byte granules (128 per CU) -- 7648 B = 6 granules -> 21 blocks, of
     // which the register budget (96 VGPRs: 5 waves per SIMD) admits 20; 19.5 KB = 16 granules -> 8; 38.9 KB = 31 granules -> 4
     case UGS_TIER_M: return launch_lds<64, 448, 64>(a, cus, part(UGS_BLOCKS_M), s, info, "ugs_walk_lds<64,448>");
+    // 704 candidates: 11.6 KB = 10 granules -> 12 blocks per CU (3 waves per SIMD: 168 VGPRs)
+    case UGS_TIER_W: return launch_lds<64, 704, 64>(a, cus, part(12), s, info, "ugs_walk_lds<64,704>");
     case UGS_TIER_X: return launch_lds<64, 1024, 64>(a, cus, part(8), s, info, "ugs_walk_lds<64,1024>");
     case UGS_TIER_L: return launch_lds<64, 2048, 64>(a, cus, part(4), s, info, "ugs_walk_lds<64,2048>");
     default: {

@@ -87,9 +87,10 @@ def _run(calls, env):
         cache.close()
 
 
-@pytest.mark.parametrize("env", [(None,), ("0",), (None, "0", "1")])
+@pytest.mark.parametrize("env", [("1",), ("0",), (None, "0", "1")])
 def test_random_minibatches_through_the_device_pass(env):
-    """default (pass on), pass off, and calls alternating between the two paths over ONE LRU history"""
+    """pass forced wherever it applies, pass off, and calls alternating between default (pass from 2048 columns on), off and forced
+    over ONE LRU history"""
     import ugs_sampler
     rng = random.Random(31337)
     pool = []
@@ -101,7 +102,7 @@ def test_random_minibatches_through_the_device_pass(env):
     if env == ("0",):
         assert built == 0
     else:
-        assert built > 100, (before, after)                                  # the pass really served the calls (repeats hit the whole-batch index)
+        assert built > (100 if env == ("1",) else 60), (before, after)       # the pass really served the calls (repeats hit the whole-batch index)
 
 
 def test_new_combinations_of_known_graphs_and_the_limits_of_the_pass():
@@ -118,7 +119,7 @@ def test_new_combinations_of_known_graphs_and_the_limits_of_the_pass():
         blocks = [ei[:, g * cols_per:(g + 1) * cols_per] - g * n_per + i * n_per for i, g in enumerate(perm)]
         calls.append((np.ascontiguousarray(np.concatenate(blocks, axis=1)), ptr, 16, 6, "sample", 42))
     s0 = ugs_sampler.batch_pass_stats()
-    _run(calls, (None,))
+    _run(calls, (None,))                                                       # 4672 columns: the default takes the pass
     s1 = ugs_sampler.batch_pass_stats()
     assert s1["device_plans"] - s0["device_plans"] == 13 and s1["general_path"] == s0["general_path"]
     rr = random.Random(8)
@@ -129,7 +130,7 @@ def test_new_combinations_of_known_graphs_and_the_limits_of_the_pass():
     calls = [(big_cols, np.array([0, 60], dtype=np.int64), 9, 4, "graph", 1), (many, np.array([0, 2501], dtype=np.int64), 9, 3, "global", 2),
              (overl, np.array([2, 6, 0, 5], dtype=np.int64), 9, 3, "global", 3),
              (np.concatenate([big_cols, ei[:, :cols_per] + 60], axis=1), np.array([0, 60, 60 + n_per], dtype=np.int64), 5, 4, "sample", 4)]
-    _run(calls, (None,))
+    _run(calls, ("1",))
     s2 = ugs_sampler.batch_pass_stats()
     assert s2["device_plans"] == s1["device_plans"] and s2["general_path"] - s1["general_path"] == 4
 
@@ -139,6 +140,7 @@ def test_lru_eviction_through_the_device_pass():
     code = r'''
 import os, sys, random
 os.environ["UGS_CACHE_SIZE"] = "3"
+os.environ["UGS_DEVICE_BATCH"] = "1"
 sys.path[:0] = [os.path.join(os.getcwd(), p) for p in ("tests", "oracle", "ss-gnn_amd")]
 import numpy as np, torch
 import oracle, ugs_sampler

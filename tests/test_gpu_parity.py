@@ -75,9 +75,9 @@ def test_random_batches_vs_oracle(product, orc):
     _same(calls, product, orc, "random batches")
 
 
-@pytest.mark.parametrize("tier", ["0", "1", "2", "3"])
+@pytest.mark.parametrize("tier", ["0", "1", "2", "3", "4"])
 def test_every_walk_tier_gives_the_same_rows(tier, product, orc, monkeypatch):
-    """UGS_FORCE_TIER pins the first walk tier (8 lanes/walk cap 64; 64 lanes cap 448 / 1024 / 2048); graphs whose
+    """UGS_FORCE_TIER pins the first walk tier (8 lanes/walk cap 64; 64 lanes cap 448 / 704 / 1024 / 2048); graphs whose
     candidate sets outgrow the tier are handed to the next one -- the rows must not depend on any of that."""
     monkeypatch.setenv("UGS_FORCE_TIER", tier)
     rng = random.Random(7 + int(tier))
@@ -91,7 +91,7 @@ def test_every_walk_tier_gives_the_same_rows(tier, product, orc, monkeypatch):
 
 @pytest.mark.parametrize("env", [{"UGS_NO_PROW": "1"}, {"UGS_PROW_SHIFT": "3"}, {"UGS_PROW_SHIFT": "6", "UGS_PROW_FIRST": "16"},
                                  {"UGS_PROW_SHIFT": "5", "UGS_PROW_FIRST": "32"}])
-@pytest.mark.parametrize("tier", ["1", "2"])
+@pytest.mark.parametrize("tier", ["1", "2", "3"])
 def test_row_layouts_of_the_wave_tiers_give_the_same_rows(env, tier, product, orc, monkeypatch):
     """The one-walk-per-wave tiers read a vertex's row from its padded block (header + first entries, the rest of the block and
     of the row on demand) or, without padded rows, through the row pointer: block sizes from 8 to 64 entries, a first fetch
@@ -387,7 +387,7 @@ print("OK")
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
 
 
-@pytest.mark.parametrize("tier", ["1", "2", "3"])
+@pytest.mark.parametrize("tier", ["1", "2", "3", "4"])
 def test_edges_staged_by_the_walk_and_the_leftover_rows(tier, product, orc, monkeypatch):
     """64-lane tiers: the walk stages up to 32 induced-edge hits per row and the fill kernel expands them; denser rows go
     to the row-reading fill kernel through a list.  Dense graphs with large k (hundreds of induced edges), multigraphs with
@@ -490,7 +490,7 @@ def test_staging_switched_off_by_its_memory_bound(product, orc, monkeypatch):
     _same(calls, product, orc, "staging off")
 
 
-@pytest.mark.parametrize("tier", [None, "1", "2"])
+@pytest.mark.parametrize("tier", [None, "1", "2", "3"])
 def test_large_launches_share_work_through_a_counter(tier, product, orc, monkeypatch):
     """Launches with many more walks than resident groups hand the walks out dynamically (chunks of 4 rows per atomicAdd);
     which wave samples a row must not matter: same rows as the oracle, and as the static split (UGS_STATIC_SPLIT)."""
@@ -605,7 +605,7 @@ def test_presample_cache_assembles_batches_like_the_reference_trainer():
             assert np.array_equal(a, b), order
 
 
-@pytest.mark.parametrize("tier", [None, "1", "2", "3"])
+@pytest.mark.parametrize("tier", [None, "1", "2", "3", "4"])
 def test_random_large_graphs_through_every_tier(tier, product, orc, monkeypatch):
     """Mid-size random multigraphs (2 000 - 20 000 vertices, degree 6 - 300, columns in one or both directions, k up to 12):
     candidate counts from a handful to more than a thousand, i.e. every variant of the order stages -- member masks of the

@@ -41,14 +41,15 @@ def _case(rng):
             rng.choice([42, 0, -7, 123456]))
 
 
-@pytest.mark.parametrize("tier", [None, "0", "1", "2", "3"])
+@pytest.mark.parametrize("tier", [None, "0", "1", "2", "3", "4"])
 def test_random_batches_under_every_first_tier(tier, monkeypatch):
     import ugs_sampler
     if tier is None:
         monkeypatch.delenv("UGS_FORCE_TIER", raising=False)
+        monkeypatch.setenv("UGS_DEVICE_BATCH", "1")          # this sequence also goes through the device batch pass wherever it applies
     else:
         monkeypatch.setenv("UGS_FORCE_TIER", tier)
-    rng = random.Random(2000 + (int(tier) if tier else 7))
+    rng = random.Random(2000 + (int(tier) if tier else 7))          # (tier "2" = the 704-candidate tier: dense 400-700-vertex graphs reach its two-pass final)
     ugs_sampler.clear_cache()
     cache = oracle.Cache()        # the reference's LRU lives across calls (its key ignores k): same call history on both sides
     for it in range(300):
