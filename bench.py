@@ -55,8 +55,9 @@ def parse_args(argv=None):
                     "previous batch (and RCCL's receive kernels) find room beside them (N > 1)")
     ap.add_argument("--walk-share-others", type=int, default=100, help="the other ranks only pack and send: their walk kernels keep the whole CU")
     ap.add_argument("--dst-rows", default="auto", help="N > 1: the destination's share of the rows.  'auto' (default): measured -- two short local "
-                    "calibration rounds in the warm-up (each rank's own work per step, no exchange), one all-gather each, then rows in proportion to "
+                    "calibration rounds in the warm-up (three; each rank's own work per step, no exchange), one all-gather each, then rows in proportion to "
                     "rows per millisecond; 'equal': the equal split; a number w: weight of the destination against 1.0 for every other rank")
+    ap.add_argument("--one-stream", action="store_true", help="N > 1: one step at a time (no second stream / buffer set / plan scratch)")
     ap.add_argument("--force-collate", action="store_true", help="run the multi-GPU collation path even with one rank (rehearsal)")
     ap.add_argument("--rehearse", action="store_true", help="N ranks on ONE GPU over gloo (every rank uses cuda:0): exercises the multi-rank control flow "
                     "of this script where only one GPU is at hand; the numbers mean nothing")
@@ -200,7 +201,13 @@ class Job:
     BESIDE the next walk: the walk kernels are persistent grids that hold their share of every CU to the end, so the collation got
     what was left (a fifth of the machine) and took up to a whole step -- the steady state then depended on how the two streams
     happened to interleave (rank-0 emulation: 0.76 ... 1.03 ms per step for neighbouring shard sizes).  Serial on one stream the
-    same kernels take 0.2 ms at full rate, and the step time is the sum of its parts: what the split calibration needs."""
+    same kernels take 0.2 ms at full rate, and the step time is the sum of its parts: what the split calibration needs.
+
+    Two steps in flight (N > 1).  A rank's shard is small (125 k rows of the 1 M: 24 walks per wave), so a step alone on the GPU
+    pays its launch ramp, its tail and four launch gaps around kernels that do not fill the chip (scan, fill, pack): a sixth of the
+    step.  Consecutive steps therefore alternate between TWO streams, each with its own buffer set and its own plan scratch
+    (Plan.twin(): same device arrays): step i+1's walk starts while step i's tail and small kernels run.  The collation chain
+    stays ordered by events: unpack(i-1) and pack(i) on step i's stream behind exchange(i-1), exchange(i) behind pack(i)."""
 
     def __init__(self, torch, dist, ud, plan, args, G, m_total, k, rank, world, dev, node_bound, n_cols, use_collate, weights=None):
         self.torch, self.plan, self.args, self.k, self.m_total = torch, plan, args, k, m_total
@@ -208,19 +215,21 @@ class Job:
         self.row_off = ud.shard_offsets(self.total_rows, world, weights)      # the same list on every rank
         self.row_begin, self.row_count = self.row_off[rank], self.row_off[rank + 1] - self.row_off[rank]
         self.use_collate = use_collate
-        self.nsets = 1                        # the pack follows the fill on the same stream: one buffer set
+        self.nsets = 2 if (use_collate and not args.one_stream) else 1     # steps alternate between two streams / buffer sets / plan scratches
         rc = self.row_count
-        self.nodes = [torch.empty((rc, k), dtype=torch.int64, device=dev)]
-        self.eptr = [torch.empty((rc + 1,), dtype=torch.int64, device=dev)]
+        self.nodes = [torch.empty((rc, k), dtype=torch.int64, device=dev) for _ in range(self.nsets)]
+        self.eptr = [torch.empty((rc + 1,), dtype=torch.int64, device=dev) for _ in range(self.nsets)]
         # edge capacity from one synchronous probe step (+5%); identical on every rank
         _, _, tot = plan.walk(m_total, args.mode, 41, self.row_begin, rc, out=(self.nodes[0], self.eptr[0]), sync=True)
         cap_t = torch.tensor([int(tot * 1.05) + 4096], dtype=torch.int64, device=dev)
         if world > 1:
             dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
         self.cap = int(cap_t.item())
-        self.eidx = [torch.empty((2, self.cap), dtype=torch.int64, device=dev)]
-        self.esrc = [torch.empty((self.cap,), dtype=torch.int64, device=dev)]
+        self.eidx = [torch.empty((2, self.cap), dtype=torch.int64, device=dev) for _ in range(self.nsets)]
+        self.esrc = [torch.empty((self.cap,), dtype=torch.int64, device=dev) for _ in range(self.nsets)]
         self.main = torch.cuda.current_stream()
+        self.streams = [self.main] + [torch.cuda.Stream(device=dev) for _ in range(self.nsets - 1)]
+        self.plans = [plan] + [plan.twin() for _ in range(self.nsets - 1)]
         if use_collate:
             self.side = torch.cuda.Stream(device=dev)
             self.collator = ud.Collator(self.total_rows, k, args.mode, node_bound, max(node_bound, m_total * k), n_cols, self.cap, dev, dst=0,
@@ -231,18 +240,21 @@ class Job:
         self.totals = None
 
     def sample(self, i):
-        """walk + scan + fill of step i (asynchronous, main stream)"""
-        self.plan.walk(self.m_total, self.args.mode, 42 + i, self.row_begin, self.row_count, out=(self.nodes[0], self.eptr[0]), sync=False)
-        self.plan.fill(self.m_total, self.nodes[0], self.eptr[0], None, self.args.mode, self.row_begin, out=(self.eidx[0], self.esrc[0]))
-        if self.totals is not None:
-            self.totals[i] = self.eptr[0][-1]
+        """walk + scan + fill of step i (asynchronous) on the stream of buffer set i % nsets"""
+        b = i % self.nsets
+        with self.torch.cuda.stream(self.streams[b]):
+            self.plans[b].walk(self.m_total, self.args.mode, 42 + i, self.row_begin, self.row_count, out=(self.nodes[b], self.eptr[b]), sync=False)
+            self.plans[b].fill(self.m_total, self.nodes[b], self.eptr[b], None, self.args.mode, self.row_begin, out=(self.eidx[b], self.esrc[b]))
+            if self.totals is not None:
+                self.totals[i] = self.eptr[b][-1]
 
-    def _unpack_previous(self):
+    def _unpack_previous(self, stream):
         """the batch whose exchange is in flight: wait for its messages (stream-side), unpack it on the destination"""
         res = None
         if self.in_flight:
-            self.main.wait_event(self.ev_exchanged)              # also: this rank's message buffer is free again
-            res = self.collator.unpack()
+            stream.wait_event(self.ev_exchanged)                 # also: this rank's message buffer is free again
+            with self.torch.cuda.stream(stream):
+                res = self.collator.unpack()
             self.in_flight = False
         return res
 
@@ -250,15 +262,17 @@ class Job:
         """this rank's part of the one exchange step, after sample(i): unpack batch i-1 (destination), pack batch i, start its
         exchange.  Returns the collated batch i-1 on the destination.  exchange=False (calibration): the same work without the
         collective -- the destination unpacks the messages already in its inbox."""
-        torch = self.torch
+        torch, b = self.torch, i % self.nsets
+        st = self.streams[b]
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(self.main)
-        res = self._unpack_previous()
-        self.collator.pack((self.nodes[0], self.eidx[0], self.eptr[0], self.esrc[0]))
-        self.ev_packed.record(self.main)
+            e0.record(st)
+        res = self._unpack_previous(st)
+        with torch.cuda.stream(st):
+            self.collator.pack((self.nodes[b], self.eidx[b], self.eptr[b], self.esrc[b]))
+        self.ev_packed.record(st)
         if timed:
-            e1.record(self.main)
+            e1.record(st)
             self.cev.append((e0, e1))
         if exchange:
             with torch.cuda.stream(self.side):
@@ -266,7 +280,7 @@ class Job:
                 self.collator.exchange()
                 self.ev_exchanged.record(self.side)
         else:
-            self.ev_exchanged.record(self.main)
+            self.ev_exchanged.record(st)
         self.in_flight = True
         return res
 
@@ -278,11 +292,13 @@ class Job:
             if self.use_collate:
                 self.collate_step(i, timed, exchange)
         if self.use_collate and count > 0:
-            res = self._unpack_previous()                        # the last batch: its exchange is exposed, as in any pipeline's drain
+            res = self._unpack_previous(self.main)               # the last batch: its exchange is exposed, as in any pipeline's drain
             self.side.synchronize()
+        for st in self.streams[1:]:                              # the caller's stream sees everything that was enqueued
+            self.main.wait_stream(st)
         return res
 
-    def local_ms_per_step(self, steps=8):
+    def local_ms_per_step(self, steps=16):
         """calibration: this rank's OWN work per step in steady state (sampling; pack; on the destination the unpack of a whole
         batch beside the next step's sampling) with no exchange, so that no rank's time contains another rank's"""
         torch = self.torch
@@ -392,9 +408,9 @@ def main():
             # Rank 0 also unpacks the whole batch, so with equal shards it is the critical path of every step.  Each round: one real
             # step (fills the destination's inbox), then every rank times its own steady-state work without the exchange; one
             # all-gather of (rows, ms); next weights = rows per millisecond.  A rank's time is rows * s + f with a fixed part f
-            # (the destination's unpack), so the proportional update is repeated once: it contracts towards equal times.
+            # (the destination's unpack), so the proportional update is repeated (three rounds): it contracts towards equal times.
             calibration = []
-            for _ in range(2):
+            for _ in range(3):
                 cj = Job(torch, dist, ud, plan, args, G, m_total, k, rank, world, dev, node_bound, ei.shape[1], True, weights)
                 cj.run_steps(0, 1)
                 torch.cuda.synchronize()

@@ -123,6 +123,9 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
 /* Plan of one preprocessing handle (the handle API's graph). */
 int ugs_plan_create_handle(int64_t handle, ugs_plan **plan_out);
 int ugs_plan_release(ugs_plan *plan);
+/* A second plan over the same device arrays with private scratch (a plan's scratch serves one stream at a time): two steps in
+ * flight on two streams go through a plan and its twin alternately.  Release both; the arrays live until the last one goes. */
+int ugs_plan_twin(ugs_plan *plan, int k, ugs_plan **twin_out);
 /* num_graphs, total vertices, total CSR entries, bytes resident in HBM, walk-kernel tier chosen for k */
 int ugs_plan_info(const ugs_plan *plan, int k, int64_t *num_graphs, int64_t *num_vertices, int64_t *nnz,
                   int64_t *device_bytes, int *tier);

@@ -19,7 +19,7 @@
 
 namespace {
 
-constexpr int kMaxK = 8;                        // (k-1)! permutations per trial, capped at 720 like the reference (:370)
+constexpr int kMaxK = 32;                       // the product's k limit (UGS_KMAX); (k-1)! permutations per trial are capped at 720 like the reference (:370)
 constexpr uint32_t kTrialCap = 1000000u;        // reference :411
 
 struct ApxParams {
@@ -33,6 +33,7 @@ struct ApxParams {
     int h_grow, h_prob;       // EstimateCuts sample counts of the two callers (:184-196)
     double ell_grow, ell_prob;
     uint64_t seed;
+    uint32_t trial_cap;       // kTrialCap; UGS_APX_TRIAL_CAP lowers it (testing aid: large k makes a complete trial expensive)
 };
 
 struct TrialRng {             // one stream per (sample, trial): splitmix64 of the key, then xorshift64*
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void ugs_apx_trials(ApxParams P, int sample0, 
     const uint32_t s = (uint32_t)(sample0 + (int)blockIdx.y);
     const uint32_t stride = gridDim.x * 256u;
     int S[kMaxK];
-    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < kTrialCap; t += stride) {
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < P.trial_cap; t += stride) {
         if (t >= __atomic_load_n(&best[blockIdx.y], __ATOMIC_RELAXED)) break;
         if (run_trial(P, s, t, S)) atomicMin(&best[blockIdx.y], t);
     }
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(64) void ugs_apx_emit(ApxParams P, int sample0, int
     const int i = (int)(blockIdx.x * 64 + threadIdx.x);
     if (i >= count) return;
     const unsigned int t = best[i];
-    if (t >= kTrialCap) return;
+    if (t >= P.trial_cap) return;
     int S[kMaxK];
     const bool ok = run_trial(P, (uint32_t)(sample0 + i), t, S);
     for (int j = 0; j < P.k; ++j) out[(int64_t)i * P.k + j] = ok ? (int64_t)S[j] : (int64_t)-1;
@@ -195,6 +196,7 @@ void cut_params(int k, double alpha, double beta, double delta, int &h, double &
 }  // namespace
 
 int ugs_internal_fail(int code, const char *msg);      // ugs_host.cpp: sets the message ugs_last_error() returns
+int ugs_internal_ctx(int *device, hipStream_t *stream);   // ugs_host.cpp: the calling thread's device and stream (ugs_set_device / ugs_set_stream)
 
 extern "C" int ugs_apx_gpu_sample_batch(const int64_t *edge_index, int64_t row_stride, int64_t num_cols, const int64_t *ptr, int64_t ptr_len,
                                         int m_per_graph, int k, uint64_t seed, double epsilon, int64_t *samples_out, int64_t *num_samples_out,
@@ -202,11 +204,12 @@ extern "C" int ugs_apx_gpu_sample_batch(const int64_t *edge_index, int64_t row_s
     using namespace ugs_apx;
     auto fail = [](int code, const char *msg) { return ugs_internal_fail(code, msg); };
     if (!ptr || ptr_len < 2 || !num_samples_out || (num_cols > 0 && !edge_index)) return fail(UGS_E_BAD_ARG, "bad arguments to apx sample_batch");
-    if (k < 2 || k > kMaxK) return fail(UGS_E_UNSUPPORTED, "the GPU variant of apx_ugs supports 2 <= k <= 8");
+    if (k < 2 || k > kMaxK) return fail(UGS_E_UNSUPPORTED, "the GPU variant of apx_ugs supports 2 <= k <= 32");
     if (!(epsilon > 0.0)) return fail(UGS_E_BAD_ARG, "epsilon must be > 0");
     *num_samples_out = 0;
-    int cnt = 0;
-    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return fail(UGS_E_NO_DEVICE, "no usable HIP device: this sampler has no CPU path");
+    int dev_id = 0;
+    hipStream_t st = nullptr;
+    if (int rc = ugs_internal_ctx(&dev_id, &st)) return rc;          // the thread's device (ugs_set_device) and stream, like every other entry point
     const int64_t c0 = std::max<int64_t>(ptr[0], 0), c1 = std::min<int64_t>(ptr[1], num_cols);
     const SimpleGraph g = read_graph(edge_index, edge_index + row_stride, c0, c1);
     if (g.n < k || m_per_graph <= 0) return UGS_OK;
@@ -228,6 +231,8 @@ extern "C" int ugs_apx_gpu_sample_batch(const int64_t *edge_index, int64_t row_s
     cut_params(k, alpha, beta, gamma / std::pow(k, 4.0), P.h_grow, P.ell_grow);
     cut_params(k, alpha, beta / std::pow(k, 6.0), rho / (k * k), P.h_prob, P.ell_prob);
     P.n = g.n; P.k = k; P.Z = Z; P.seed = seed;
+    P.trial_cap = kTrialCap;
+    if (const char *ev = std::getenv("UGS_APX_TRIAL_CAP")) { const long c = std::atol(ev); if (c > 0 && c < (long)kTrialCap) P.trial_cap = (uint32_t)c; }
     P.accept_scale = (beta / Z) * std::pow(k, static_cast<double>(-C1));
     // device copies
     std::vector<int> pos32(o.pos.begin(), o.pos.end());
@@ -245,8 +250,8 @@ extern "C" int ugs_apx_gpu_sample_batch(const int64_t *edge_index, int64_t row_s
     if ((e = hipMemcpy(d + o_pos, pos32.data(), b_pos, hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
     if ((e = hipMemcpy(d + o_est, o.est.data(), b_d, hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
     if ((e = hipMemcpy(d + o_cum, cum.data(), b_d, hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
-    if ((e = hipMemset(d + o_best, 0xFF, (size_t)m_per_graph * sizeof(unsigned int))) != hipSuccess) return bail(e);
-    if ((e = hipMemset(d + o_out, 0xFF, (size_t)m_per_graph * k * sizeof(int64_t))) != hipSuccess) return bail(e);
+    if ((e = hipMemsetAsync(d + o_best, 0xFF, (size_t)m_per_graph * sizeof(unsigned int), st)) != hipSuccess) return bail(e);
+    if ((e = hipMemsetAsync(d + o_out, 0xFF, (size_t)m_per_graph * k * sizeof(int64_t), st)) != hipSuccess) return bail(e);
     P.off = reinterpret_cast<const int64_t *>(d); P.nbr = reinterpret_cast<const int *>(d + o_nbr); P.pos = reinterpret_cast<const int *>(d + o_pos);
     P.est = reinterpret_cast<const double *>(d + o_est); P.cum = reinterpret_cast<const double *>(d + o_cum);
     unsigned int *best = reinterpret_cast<unsigned int *>(d + o_best);
@@ -256,12 +261,13 @@ extern "C" int ugs_apx_gpu_sample_batch(const int64_t *edge_index, int64_t row_s
     for (int s0 = 0; s0 < m_per_graph; s0 += slab) {
         const int ns = std::min(slab, m_per_graph - s0);
         int gx = std::max(1, std::min(64, 8192 / ns));
-        hipLaunchKernelGGL(ugs_apx_trials, dim3((unsigned)gx, (unsigned)ns), dim3(256), 0, 0, P, s0, best + s0);
-        hipLaunchKernelGGL(ugs_apx_emit, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, 0, P, s0, ns, best + s0, out + (int64_t)s0 * k);
+        hipLaunchKernelGGL(ugs_apx_trials, dim3((unsigned)gx, (unsigned)ns), dim3(256), 0, st, P, s0, best + s0);
+        hipLaunchKernelGGL(ugs_apx_emit, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, st, P, s0, ns, best + s0, out + (int64_t)s0 * k);
         if ((e = hipGetLastError()) != hipSuccess) return bail(e);
     }
     std::vector<int64_t> h_out((size_t)m_per_graph * k);
-    if ((e = hipMemcpy(h_out.data(), out, h_out.size() * sizeof(int64_t), hipMemcpyDeviceToHost)) != hipSuccess) return bail(e);
+    if ((e = hipMemcpyAsync(h_out.data(), out, h_out.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return bail(e);
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return bail(e);
     (void)hipFree(d);
     int64_t got = 0;
     for (int s = 0; s < m_per_graph; ++s) {

@@ -55,6 +55,7 @@ int fail(int code, const std::string &msg) { t_err = msg; return code; }
 }  // namespace
 // the other translation units of the library report through the same thread-local message (internal, not part of the C ABI)
 int ugs_internal_fail(int code, const char *msg) { return fail(code, msg ? msg : ""); }
+int ugs_internal_ctx(int *device, hipStream_t *stream);    // below: the calling thread's device and stream (ugs_set_device / ugs_set_stream)
 namespace {
 int fail_hip(hipError_t e, const char *what) { return fail(UGS_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail_hip(e_, #expr); } while (0)
@@ -382,6 +383,16 @@ int device_ctx(DeviceCtx &out) {
     return UGS_OK;
 }
 
+}  // namespace
+int ugs_internal_ctx(int *device, hipStream_t *stream) {
+    DeviceCtx dc;
+    if (int rc = device_ctx(dc)) return rc;
+    if (device) *device = dc.id;
+    if (stream) *stream = dc.stream;
+    return UGS_OK;
+}
+namespace {
+
 // grow-only device scratch pool (per process): avoids hipMalloc/hipFree on every call
 struct PoolBuf { void *p = nullptr; size_t bytes = 0; int dev = -1; };
 std::mutex g_pool_mu;
@@ -454,6 +465,7 @@ struct ugs_plan {
     hipStream_t last_stream = nullptr;
     bool last_valid = false;
     PoolBuf prow;                         // padded rows (ugs_device.h), built on the device by the first walk in a one-walk-per-wave tier
+    std::atomic<size_t> prow_bytes{0};    // their size, readable by the plan cache without this plan's mutex
     bool prow_pooled = false, prow_failed = false;
     int walk_share = 100;                 // ugs_plan_set_walk_share
     bool stg_valid = false;
@@ -463,6 +475,7 @@ struct ugs_plan {
     int64_t gws_groups = 0, gws_words = 0;
     int gcap = 0, ghs = 0, gbcap = 0, gpcap = 0;
     std::vector<std::shared_ptr<void>> keep;   // device-built plans point into their graphs' arena entries: the graphs live as long as the plan
+    ugs_plan *twin_of = nullptr;               // ugs_plan_twin: the plan whose device arrays this one shares (it holds a reference)
     UgsLaunchInfo last_walk{nullptr, 0, 0, 0};
     UgsLaunchInfo last_fill{nullptr, 0, 0, 0};
     int64_t last_overflow = 0;
@@ -654,7 +667,9 @@ void destroy_plan(ugs_plan *p) {
     pool_put(p->stage); pool_put(p->ulist); pool_put(p->work);
     if (p->prow.p) { if (p->prow_pooled) pool_put(p->prow); else (void)hipFree(p->prow.p); p->prow = PoolBuf(); }
     if (p->gws.p) { (void)hipFree(p->gws.p); p->gws = PoolBuf(); }
+    ugs_plan *owner = p->twin_of;
     delete p;
+    if (owner && owner->refs.fetch_sub(1) == 1) destroy_plan(owner);
 }
 }  // namespace
 namespace { void plan_unref(ugs_plan *p) { if (p && p->refs.fetch_sub(1) == 1) destroy_plan(p); } }
@@ -685,11 +700,26 @@ void plan_cache_put(ugs_plan *p) {
         p->cached = true;
         g_plan_cache.push_front(p);
         size_t bytes = 0;
-        for (auto *q : g_plan_cache) bytes += q->blob_bytes + q->prow.bytes;
+        for (auto *q : g_plan_cache) bytes += q->blob_bytes + q->prow_bytes.load();
         while (g_plan_cache.size() > g_plan_cache_cap || (bytes > g_plan_cache_bytes_cap && g_plan_cache.size() > 1)) {
             ugs_plan *v = g_plan_cache.back();
             g_plan_cache.pop_back();
-            bytes -= v->blob_bytes + v->prow.bytes;
+            bytes -= v->blob_bytes + v->prow_bytes.load();
+            victims.push_back(v);
+        }
+    }
+    for (auto *v : victims) plan_unref(v);
+}
+void plan_cache_trim() {      // after a cached plan grew (padded rows built lazily): apply the byte cap again
+    std::vector<ugs_plan *> victims;
+    {
+        std::lock_guard<std::mutex> lk(g_pc_mu);
+        size_t bytes = 0;
+        for (auto *q : g_plan_cache) bytes += q->blob_bytes + q->prow_bytes.load();
+        while (bytes > g_plan_cache_bytes_cap && g_plan_cache.size() > 1) {
+            ugs_plan *v = g_plan_cache.back();
+            g_plan_cache.pop_back();
+            bytes -= v->blob_bytes + v->prow_bytes.load();
             victims.push_back(v);
         }
     }
@@ -753,8 +783,12 @@ void hash_array(const int64_t *p, int64_t n, Hash128 &h) {
     const int64_t hw = (int64_t)std::thread::hardware_concurrency();
     const int64_t T = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nch, 8), hw > 0 ? hw : 1));
     std::vector<std::thread> helpers;
-    for (int64_t t = 1; t < T; ++t) helpers.emplace_back(work, t, T);
+    int64_t started = 1;                                                       // strides taken by a thread: 0 (this one), 1 .. started-1
+    try {
+        for (int64_t t = 1; t < T; ++t) { helpers.emplace_back(work, t, T); started = t + 1; }
+    } catch (...) {}                                                           // std::system_error must not cross the C ABI: this thread does the rest
     work(0, T);
+    for (int64_t t = started; t < T; ++t) work(t, T);
     for (auto &th : helpers) th.join();
     static_assert(sizeof(Hash128) == 2 * sizeof(int64_t), "chunk hashes are hashed as words");
     hash_words(reinterpret_cast<const int64_t *>(part.data()), 2 * nch, h);
@@ -883,6 +917,8 @@ int ensure_prow(ugs_plan *plan, hipStream_t s) {
     int first = (int)std::ceil((sb + 0.5 * std::sqrt(sb) + 1.0) / 16.0) * 16;
     if (const char *e = std::getenv("UGS_PROW_FIRST")) { const int f = std::atoi(e); if (f >= 1) first = f; }
     plan->dev.prow_first = std::max(1, std::min(first, 1 << shift));
+    plan->prow_bytes.store(plan->prow.bytes);
+    if (plan->cached) plan_cache_trim();        // the cache admitted the plan without these bytes: apply its byte cap again
     return UGS_OK;
 }
 
@@ -890,7 +926,7 @@ int ensure_prow(ugs_plan *plan, hipStream_t s) {
 // plan's last call has to be over first (rare: sizes settle after the first calls).
 int ensure(PoolBuf &b, size_t bytes, int dev, ugs_plan *plan) {
     if (b.p && b.bytes >= bytes) return UGS_OK;
-    if (b.p && plan && plan->last_valid) HIP_TRY(hipStreamSynchronize(plan->last_stream));
+    if (b.p && plan && plan->last_valid) HIP_TRY(hipEventSynchronize(plan->last_ev));     // the event, not the caller's stream handle (which may be gone)
     pool_put(b);
     return pool_get(bytes, dev, b);
 }
@@ -1015,10 +1051,11 @@ int graph_dev_roots(Graph &g, int dev, RootArena *ar, hipStream_t s, Graph::DevR
 }
 
 // UGS_DEVICE_BATCH: 0 = never, 1 = whenever applicable, unset = whenever applicable and the batch has at least
-// kBatchPassMinCols columns.  Below that the chain upload -> kernel -> keys back (~30 us of latencies) costs more than the host's
-// own pass over a few hundred columns (measured, C2 / C4 shapes: 0.15 against 0.13 ms per call); above it the pass wins (C3 shape,
-// 4672 columns: 0.276 against 0.295 ms host-visible, 0.189 against 0.197 ms with device outputs).
-constexpr int64_t kBatchPassMinCols = 2048;
+// kBatchPassMinCols columns.  The chain upload -> kernel -> keys back costs ~25 us of latencies whatever the size; around 1200
+// columns (MUTAG- / QM9-shaped batches of 32 graphs) that equals the host's own pass + plan assembly (0.138 against 0.138 ms and
+// 0.717 against 0.717 ms per call), at 4672 columns (PROTEINS-shaped) the pass wins (0.279 against 0.298 ms host-visible, 0.195
+// against 0.203 ms with device outputs); below ~1000 columns the host is faster.
+constexpr int64_t kBatchPassMinCols = 1024;
 int device_batch_mode() {
     const char *e = std::getenv("UGS_DEVICE_BATCH");
     if (e && e[0] == '0') return 0;
@@ -1651,9 +1688,22 @@ int ugs_plan_graph_create(ugs_plan *plan, int m_per_graph, int k, int mode, int6
     g->device = plan->device;
     plan->refs.fetch_add(1);
     g->owner = plan;
+    {   // the padded rows belong to the OWNER (one copy, counted against the plan cache): build them before the shadow copies `dev`
+        const TierChoice tc0 = choose_tier(plan, k);
+        std::lock_guard<std::mutex> lk(plan->mu);
+        if ((tc0.first != UGS_TIER_S && tc0.first != UGS_TIER_G) || tc0.second >= 0) {
+            DeviceCtx dc0;
+            if (int rc = device_ctx(dc0)) { plan_unref(plan); delete g; return rc; }
+            if (int rc = ensure_prow(plan, dc0.stream)) { plan_unref(plan); delete g; return rc; }
+        }
+    }
     auto *sh = new ugs_plan();
     sh->device = plan->device; sh->cus = plan->cus; sh->G = plan->G; sh->nverts = plan->nverts; sh->nnz = plan->nnz;
-    sh->dev = plan->dev;             // device arrays shared, not owned (blob stays null)
+    {
+        std::lock_guard<std::mutex> lk(plan->mu);
+        sh->dev = plan->dev;         // device arrays shared, not owned (blob stays null)
+    }
+    sh->prow_failed = true;          // never a private copy of the padded rows: the owner's, or the row-pointer path
     sh->g_n = plan->g_n; sh->g_maxdeg = plan->g_maxdeg; sh->g_sbdeg = plan->g_sbdeg; sh->g_level = plan->g_level;
     sh->walk_share = plan->walk_share;
     g->shadow = sh;
@@ -1690,6 +1740,37 @@ int ugs_plan_graph_create(ugs_plan *plan, int m_per_graph, int k, int mode, int6
     if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
     if (e != hipSuccess) return bail(fail_hip(e, "building the graph"));
     *graph_out = g;
+    return UGS_OK;
+}
+
+// A second plan over the SAME device arrays with scratch of its own: calls on a plan are serialised through its scratch (one
+// stream at a time), so a caller that wants two steps in flight -- the next batch's walk filling the tail of this one's, on
+// another stream -- samples them through a plan and its twin alternately.
+int ugs_plan_twin(ugs_plan *plan, int k, ugs_plan **twin_out) {
+    if (!plan || !twin_out) return fail(UGS_E_BAD_ARG, "null argument");
+    HIP_TRY(hipSetDevice(plan->device));
+    {   // the padded rows belong to the owner: build them before the twin copies `dev`
+        const TierChoice tc0 = choose_tier(plan, k);
+        std::lock_guard<std::mutex> lk(plan->mu);
+        if ((tc0.first != UGS_TIER_S && tc0.first != UGS_TIER_G) || tc0.second >= 0) {
+            DeviceCtx dc0;
+            if (int rc = device_ctx(dc0)) return rc;
+            if (int rc = ensure_prow(plan, dc0.stream)) return rc;
+        }
+    }
+    auto *sh = new ugs_plan();
+    sh->device = plan->device; sh->cus = plan->cus; sh->G = plan->G; sh->nverts = plan->nverts; sh->nnz = plan->nnz;
+    {
+        std::lock_guard<std::mutex> lk(plan->mu);
+        sh->dev = plan->dev;
+        sh->walk_share = plan->walk_share;
+    }
+    sh->g_n = plan->g_n; sh->g_maxdeg = plan->g_maxdeg; sh->g_sbdeg = plan->g_sbdeg; sh->g_level = plan->g_level;
+    sh->handle_api = plan->handle_api;
+    sh->prow_failed = true;
+    plan->refs.fetch_add(1);
+    sh->twin_of = plan;
+    *twin_out = sh;
     return UGS_OK;
 }
 

@@ -96,11 +96,12 @@ def _select_device(device, jobs=False):
         check(lib.ugs_set_device(idx))
         if jobs:
             check(lib.ugs_set_stream(torch.cuda.current_stream(idx).cuda_stream, 1))
+        else:
+            check(lib.ugs_set_stream(None, 0))       # only a device job runs on the caller's stream: a stale handle must not outlive it
     else:
         if torch.cuda.is_available():
             check(lib.ugs_set_device(torch.cuda.current_device()))
-        if jobs:
-            check(lib.ugs_set_stream(None, 0))
+        check(lib.ugs_set_stream(None, 0))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -305,6 +306,14 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+    def twin(self):
+        """A second Plan over the same device arrays with scratch of its own.  Calls on one plan are serialised through its
+        scratch; sampling consecutive batches through a plan and its twin on two streams keeps two steps in flight, so that the
+        next batch's walk fills the tail (and the small kernels) of this one's."""
+        h = vp()
+        check(lib.ugs_plan_twin(self._h, self.k, C.byref(h)))
+        return Plan(h, self.num_graphs, self.k)
 
     def info(self):
         g, nv, nnz, nb, tier = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()

@@ -212,9 +212,9 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["global_rows"] == 100_000
-    # the destination-aware split (default --dst-rows auto): two calibration rounds, the first on the equal split; the ranks' rows cover the batch
+    # the destination-aware split (default --dst-rows auto): three calibration rounds, the first on the equal split; the ranks' rows cover the batch
     pr, cal = line["per_rank"], line["split_calibration"]
-    assert len(cal) == 2 and cal[0]["rows"] == [50_000, 50_000] and sum(cal[1]["rows"]) == 100_000
+    assert len(cal) == 3 and cal[0]["rows"] == [50_000, 50_000] and sum(cal[1]["rows"]) == 100_000 and sum(cal[2]["rows"]) == 100_000
     assert [p_["rank"] for p_ in pr] == [0, 1] and sum(p_["rows"] for p_ in pr) == 100_000 and line["config"]["rows_per_gpu"] == pr[0]["rows"]
     assert pr[0]["walk_share"] == 80 and pr[1]["walk_share"] == 100 and all(p_["walk_ms"] > 0 for p_ in pr)
     assert line["collate_ms_per_step"] is not None and line["extras"]["weak_scaling"]["global_rows"] == 200_000
