@@ -125,11 +125,12 @@ struct UgsLaunchInfo {
 
 // tiers of the walk kernel: candidate-set capacity held in LDS per walk, lanes per walk
 enum { UGS_TIER_S = 0 /* cap 64, 8 lanes */, UGS_TIER_M = 1 /* cap 448, 64 lanes */, UGS_TIER_W = 2 /* cap 704, 64 lanes, half-size bucket table */,
-       UGS_TIER_X = 3 /* cap 1024, 64 lanes */, UGS_TIER_L = 4 /* cap 2048, 64 lanes */, UGS_TIER_G = 5 /* global-memory workspace, 64 lanes */ };
-#define UGS_LDS_TIERS 5
-static constexpr int UGS_TIER_CAP[UGS_LDS_TIERS] = {64, 448, 704, 1024, 2048};
-static constexpr int UGS_TIER_LANES[UGS_LDS_TIERS] = {8, 64, 64, 64, 64};              // lanes per walk
-static constexpr int UGS_TIER_HASH_LIMIT[UGS_LDS_TIERS] = {96, 448, 896, 1536, 3072};  // TierCfg<CAP>::HLIMIT (static_assert in ugs_kernels.hip)
+       UGS_TIER_X = 3 /* cap 1024, 64 lanes */, UGS_TIER_V = 4 /* cap 1408, 64 lanes, third-size bucket table */, UGS_TIER_L = 5 /* cap 2048, 64 lanes */,
+       UGS_TIER_G = 6 /* global-memory workspace, 64 lanes */ };
+#define UGS_LDS_TIERS 6
+static constexpr int UGS_TIER_CAP[UGS_LDS_TIERS] = {64, 448, 704, 1024, 1408, 2048};
+static constexpr int UGS_TIER_LANES[UGS_LDS_TIERS] = {8, 64, 64, 64, 64, 64};                // lanes per walk
+static constexpr int UGS_TIER_HASH_LIMIT[UGS_LDS_TIERS] = {96, 448, 896, 1536, 1792, 3072};  // TierCfg<CAP>::HLIMIT (static_assert in ugs_kernels.hip)
 
 hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int device_cus, int share_percent, hipStream_t s, UgsLaunchInfo *info);
 hipError_t ugs_launch_build_prow(const UgsPlanDev &plan, int64_t num_vertices, int2 *prow, int shift, int device_cus, hipStream_t s);

@@ -735,13 +735,15 @@ __device__ __forceinline__ Pick stage_final(const Work<LdsSpace> &ws, const Grp<
 // B, the multiply-shift constants and the order-array offsets are immediates (no scalar loads from the chain table, no
 // waits on them), the elements-per-lane variant of a materialising stage is fixed at compile time, and a final stage only
 // carries the variants its candidate range (B[stage-1], min(B[stage], CAP)] can need.
-constexpr int nj_of(int per) { return per <= 1 ? 1 : per <= 3 ? 3 : per <= 5 ? 5 : per <= 7 ? 7 : per <= 9 ? 9 : per <= 13 ? 13 : per <= 17 ? 17 : 33; }
+constexpr int nj_of(int per) { return per <= 1 ? 1 : per <= 3 ? 3 : per <= 5 ? 5 : per <= 7 ? 7 : per <= 9 ? 9 : per <= 13 ? 13 : per <= 17 ? 17 : per <= 19 ? 19 : 33; }
 constexpr int nst_of(int cap) { return cap <= 64 ? 3 : (cap <= 512 ? 5 : (cap <= 1024 ? 6 : 7)); }       // stages that are ever materialised
 // Bucket-table words of a tier.  Normally the smallest chain value >= CAP (the final stage's buckets in one piece).  The 704-candidate
 // tier keeps only HALF of its final stage's 1109 + 1 slots (stage_final runs two passes there) and lets the 541-bucket stage put its
 // position lists into its own order array: 11.6 KB per walk instead of 19.4 KB, 12 walks per CU instead of 8.
-constexpr int tier_index(int cap) { return cap <= 64 ? 0 : (cap <= 512 ? 1 : (cap <= 704 ? 2 : (cap <= 1024 ? 3 : 4))); }
-constexpr int tbl_words(int cap) { constexpr int w[5] = {127, 541, 555, 1109, 2357}; return (w[tier_index(cap)] + 3) & ~3; }
+// The 1408-candidate tier likewise keeps the 1109 words its largest materialising stage needs and runs its final stage (2357 + 1
+// slots) in three passes: 23.2 KB per walk instead of 38.9 KB, 6 walks per CU instead of 4.
+constexpr int tier_index(int cap) { return cap <= 64 ? 0 : (cap <= 512 ? 1 : (cap <= 704 ? 2 : (cap <= 1024 ? 3 : (cap <= 1408 ? 4 : 5)))); }
+constexpr int tbl_words(int cap) { constexpr int w[6] = {127, 541, 555, 1109, 1109, 2357}; return (w[tier_index(cap)] + 3) & ~3; }
 
 template <int STAGE> struct ChainAt {
     static constexpr uint32_t B = kChainHost[STAGE], M = cmagic(kChainHost[STAGE]), S = (uint32_t)clog2(kChainHost[STAGE]) - 1u;
@@ -784,7 +786,7 @@ __device__ __forceinline__ Pick final_at(const Work<LdsSpace> &ws, const Grp<GS>
     // register-ranked final (78 VALU instructions against 59 + 7 LDS operations for the table variant: the shorter dependency
     // chain wins); from 65 on the bucket-table variant with exactly ceil(c/64) elements per lane -- for 65..128 candidates it
     // takes 93 VALU instructions where ranking two elements per lane in registers took 207 (7.16 -> 7.01 ms per 1M walks).
-    constexpr int PASSES = (int)C::B + 1 > tbl_words((int)CAP) ? 2 : 1;          // the table holds the stage's slots 0 .. B in one piece, or half of them
+    constexpr int PASSES = ((int)C::B + tbl_words((int)CAP)) / tbl_words((int)CAP);   // the table holds the stage's slots 0 .. B in one piece, or a half / a third of them
     static_assert(((int)C::B + PASSES) / PASSES <= tbl_words((int)CAP), "a pass of the final stage must fit the tier's bucket table");
 #define UGS_FINAL_LDS(LO, HI, NJ) UGS_FINAL_CASE(LO, HI, (stage_final<GS, NJ, PASSES>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
     if constexpr (GS == 64) {
@@ -793,7 +795,7 @@ __device__ __forceinline__ Pick final_at(const Work<LdsSpace> &ws, const Grp<GS>
     } else {
         UGS_FINAL_LDS(1, 1, 1) UGS_FINAL_LDS(2, 3, 3) UGS_FINAL_LDS(4, 5, 5) UGS_FINAL_LDS(6, 7, 7)
     }
-    UGS_FINAL_LDS(8, 9, 9) UGS_FINAL_LDS(10, 11, 11) UGS_FINAL_LDS(12, 13, 13) UGS_FINAL_LDS(14, 17, 17) UGS_FINAL_LDS(18, 1 << 20, 33)
+    UGS_FINAL_LDS(8, 9, 9) UGS_FINAL_LDS(10, 11, 11) UGS_FINAL_LDS(12, 13, 13) UGS_FINAL_LDS(14, 17, 17) UGS_FINAL_LDS(18, 22, 22) UGS_FINAL_LDS(23, 1 << 20, 33)
 #undef UGS_FINAL_LDS
 #undef UGS_FINAL_CASE
     return Pick{0u, 0u};
@@ -1208,8 +1210,8 @@ template <int CAP> struct TierCfg {
     static constexpr int ORDW = (int)(((ord_words_before(NSTAGE) + 1u) / 2u + 3u) & ~3u);   // 16-bit positions: 52 / 248 / 520 / 1072 words
     static constexpr int TI = tier_index(CAP);
     static constexpr int BCAP_A = tbl_words(CAP);                                   // bucket-table words (see tbl_words)
-    static constexpr int HS = TI == 0 ? 128 : (TI == 1 ? 512 : (TI == 2 ? 1024 : (TI == 3 ? 2048 : 4096)));
-    static constexpr int HLIMIT = (TI == 1 || TI == 2) ? HS / 8 * 7 : HS / 4 * 3;   // max distinct vertices a walk may have seen
+    static constexpr int HS = TI == 0 ? 128 : (TI == 1 ? 512 : (TI == 2 ? 1024 : (TI <= 4 ? 2048 : 4096)));
+    static constexpr int HLIMIT = (TI == 1 || TI == 2 || TI == 4) ? HS / 8 * 7 : HS / 4 * 3;   // max distinct vertices a walk may have seen
     static_assert(CAP <= 64 || BCAP_A * 4 >= 127 * 16, "mates2_by_table keeps 16 bytes per bucket of the 127-bucket stage in TBL");
     static_assert(HLIMIT == UGS_TIER_HASH_LIMIT[TI] && CAP == UGS_TIER_CAP[TI], "host tier logic (choose_tier) relies on these limits");
     static constexpr int ELW = CAP > 64 ? 4 * UGS_STAGE_ENTRIES : 0;             // staged hits (one-walk-per-wave tiers)
@@ -1222,7 +1224,7 @@ template <int CAP> struct TierCfg {
 // (10.63 vs 10.43 ms: a launch ended with the waves of the fuller SIMDs); with the shared work counter the extra waves are
 // pure throughput: 8.81 -> 8.51 ms.  Spilling further to reach more waves costs more than it brings (30 % in an early build).
 template <int GS, int CAP, int BLOCK, bool PAD>
-__global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP == 704 ? 3 : (CAP <= 64 || CAP == 1024 ? 2 : 1))) void ugs_walk_lds(UgsWalkArgs a) {
+__global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP == 704 ? 3 : (CAP <= 64 || CAP == 1024 || CAP == 1408 ? 2 : 1))) void ugs_walk_lds(UgsWalkArgs a) {
     using Cfg = TierCfg<CAP>;
     constexpr int GROUPS = BLOCK / GS;
     __shared__ __attribute__((aligned(16))) uint32_t lds[GROUPS * Cfg::WORDS];
@@ -1658,6 +1660,8 @@ hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, int share_pe
     // 704 candidates: 11.6 KB = 10 granules -> 12 blocks per CU (3 waves per SIMD: 168 VGPRs)
     case UGS_TIER_W: return launch_lds<64, 704, 64>(a, cus, part(12), s, info, "ugs_walk_lds<64,704>");
     case UGS_TIER_X: return launch_lds<64, 1024, 64>(a, cus, part(8), s, info, "ugs_walk_lds<64,1024>");
+    // 1408 candidates: 23.2 KB = 19 granules -> 6 blocks per CU (2 waves per SIMD: 256 VGPRs)
+    case UGS_TIER_V: return launch_lds<64, 1408, 64>(a, cus, part(6), s, info, "ugs_walk_lds<64,1408>");
     case UGS_TIER_L: return launch_lds<64, 2048, 64>(a, cus, part(4), s, info, "ugs_walk_lds<64,2048>");
     default: {
         int64_t grid = a.gws_words_per_group > 0 ? a.gws_groups : 0;

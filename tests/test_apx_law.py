@@ -1,7 +1,8 @@
 """CPU: the enumerated output law of APX-UGS (oracle/apx_oracle.py) pinned against the sequential restatement csrc/ugs_apx.cpp,
 which is bit-exact with the reference (tests/test_apx_entry.py).  The restatement needs minutes of CPU per hundred samples (the
 reference's acceptance probability is ~3e-6 per trial), so its rows were drawn once in the build container and are committed as
-counts (tests/golden/apx_host_counts.json); this test recomputes the law and checks counts, support and failure rate against it.
+counts (tests/golden/apx_host_counts.json, generator: oracle/make_golden_apx_counts.py -- from the reference module itself when
+oracle/_ref is present); this test recomputes the law and checks counts, support and failure rate against it, for k = 3 and k = 4.
 tests/test_gpu_apx.py then holds the GPU variant to the same law."""
 import json
 import os
@@ -27,6 +28,36 @@ def test_sequential_restatement_follows_the_enumerated_law():
         pval, chi2, dof = ao.chi_square_p(counts, law)
         assert pval > 1e-3, f"{name}: chi2 {chi2:.1f} on {dof} dof, p = {pval:.2e}"
         # samples without an accepted trial among 10^6 are dropped (reference :411, :450-453)
+        p_fail = (1.0 - acc) ** 1_000_000
+        assert abs((g["requested"] - got) - g["requested"] * p_fail) <= 5.0 * np.sqrt(g["requested"] * p_fail * (1 - p_fail)) + 3
+
+
+def test_sequential_rows_follow_the_law_for_k4():
+    """k = 4 on the kite graph: the committed rows of the sequential sampler (fixture section "k4", generator
+    oracle/make_golden_apx_counts.py) against apx_oracle.law_k -- root and growth factors enumerated, the acceptance factor over 2e5
+    joint draws of its 36 binomials; law_k itself is checked against the full enumeration law_k3 on k = 3."""
+    import apx_oracle as ao
+    fix = json.load(open(os.path.join(ROOT, "tests", "golden", "apx_host_counts.json")))
+    # law_k == law_k3 on k = 3 (the Monte-Carlo factor agrees with its exact value to a fraction of a percent)
+    g3 = fix["graphs"]["kite"]
+    adj = ao.adjacency(5, [tuple(e) for e in g3["edges"]])
+    pos, est = ao.order(adj, 3, fix["epsilon"])
+    exact, acc3 = ao.law_k3(adj, pos, est, fix["epsilon"])
+    mc, acc3k = ao.law_k(adj, pos, est, fix["epsilon"], 3)
+    assert set(exact) == set(mc) and max(abs(mc[s] - exact[s]) / exact[s] for s in exact) < 0.01 and abs(acc3k - acc3) / acc3 < 0.01
+    sec = fix["k4"]
+    eps, k = sec["epsilon"], sec["k"]
+    assert k == 4
+    for name, g in sec["graphs"].items():
+        edges = [tuple(e) for e in g["edges"]]
+        adj = ao.adjacency(max(max(e) for e in edges) + 1, edges)
+        pos, est = ao.order(adj, k, eps)
+        law, acc = ao.law_k(adj, pos, est, eps, k)
+        counts = {tuple(key): v for key, v in g["counts"]}
+        got = sum(counts.values())
+        assert got >= 150
+        pval, chi2, dof = ao.chi_square_p(counts, law)
+        assert pval > 1e-3, f"{name} k=4: chi2 {chi2:.1f} on {dof} dof, p = {pval:.2e}"
         p_fail = (1.0 - acc) ** 1_000_000
         assert abs((g["requested"] - got) - g["requested"] * p_fail) <= 5.0 * np.sqrt(g["requested"] * p_fail * (1 - p_fail)) + 3
 

@@ -75,9 +75,9 @@ def test_random_batches_vs_oracle(product, orc):
     _same(calls, product, orc, "random batches")
 
 
-@pytest.mark.parametrize("tier", ["0", "1", "2", "3", "4"])
+@pytest.mark.parametrize("tier", ["0", "1", "2", "3", "4", "5"])
 def test_every_walk_tier_gives_the_same_rows(tier, product, orc, monkeypatch):
-    """UGS_FORCE_TIER pins the first walk tier (8 lanes/walk cap 64; 64 lanes cap 448 / 704 / 1024 / 2048); graphs whose
+    """UGS_FORCE_TIER pins the first walk tier (8 lanes/walk cap 64; 64 lanes cap 448 / 704 / 1024 / 1408 / 2048); graphs whose
     candidate sets outgrow the tier are handed to the next one -- the rows must not depend on any of that."""
     monkeypatch.setenv("UGS_FORCE_TIER", tier)
     rng = random.Random(7 + int(tier))
@@ -387,7 +387,7 @@ print("OK")
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
 
 
-@pytest.mark.parametrize("tier", ["1", "2", "3", "4"])
+@pytest.mark.parametrize("tier", ["1", "2", "3", "4", "5"])
 def test_edges_staged_by_the_walk_and_the_leftover_rows(tier, product, orc, monkeypatch):
     """64-lane tiers: the walk stages up to 32 induced-edge hits per row and the fill kernel expands them; denser rows go
     to the row-reading fill kernel through a list.  Dense graphs with large k (hundreds of induced edges), multigraphs with
@@ -605,7 +605,7 @@ def test_presample_cache_assembles_batches_like_the_reference_trainer():
             assert np.array_equal(a, b), order
 
 
-@pytest.mark.parametrize("tier", [None, "1", "2", "3", "4"])
+@pytest.mark.parametrize("tier", [None, "1", "2", "3", "4", "5"])
 def test_random_large_graphs_through_every_tier(tier, product, orc, monkeypatch):
     """Mid-size random multigraphs (2 000 - 20 000 vertices, degree 6 - 300, columns in one or both directions, k up to 12):
     candidate counts from a handful to more than a thousand, i.e. every variant of the order stages -- member masks of the

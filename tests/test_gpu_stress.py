@@ -41,7 +41,7 @@ def _case(rng):
             rng.choice([42, 0, -7, 123456]))
 
 
-@pytest.mark.parametrize("tier", [None, "0", "1", "2", "3", "4"])
+@pytest.mark.parametrize("tier", [None, "0", "1", "2", "3", "4", "5"])
 def test_random_batches_under_every_first_tier(tier, monkeypatch):
     import ugs_sampler
     if tier is None:
