@@ -167,3 +167,23 @@ print("OK")
 '''
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=200)
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_many_small_graphs_take_the_two_kernel_variant():
+    """G * E above 4 M: the slicing runs as a kernel of its own (thread per column, binary search in ptr, wave-aggregated atomics)
+    and the build kernel compacts only the span of its graph -- 900 graphs, shuffled columns, stray columns, against the oracle"""
+    rng = random.Random(99)
+    cols, ptr = [], [0]
+    for g in range(900):
+        n = rng.choice([0, 2, 4, 5, 6, 7, 9])
+        e = [(u + ptr[-1], v + ptr[-1]) for u in range(n) for v in range(u + 1, n) if rng.random() < 0.5]
+        cols += e + [(v, u) for u, v in e]
+        ptr.append(ptr[-1] + n)
+    cols += [(rng.randrange(ptr[-1]), rng.randrange(ptr[-1])) for _ in range(50)]
+    rng.shuffle(cols)
+    ei = np.array(cols, dtype=np.int64).T.reshape(2, -1).copy()
+    assert 900 * ei.shape[1] > (4 << 20)
+    import ugs_sampler
+    s0 = ugs_sampler.batch_pass_stats()
+    _run([(ei, np.array(ptr, dtype=np.int64), 3, 4, "sample", 42), (ei[:, ::-1].copy(), np.array(ptr, dtype=np.int64), 2, 3, "global", 7)], ("1",))
+    assert ugs_sampler.batch_pass_stats()["device_plans"] - s0["device_plans"] == 2
