@@ -744,8 +744,8 @@ def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
         ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode="sample", seed=42)
     dt_host = (time.perf_counter() - t) / reps
     # shuffled mini-batches: every call is a NEW combination of already-seen graphs (per-graph LRU hits, no plan to reuse): what a
-    # trainer's DataLoader produces every step.  Three disjoint sets of such batches, each batch timed once: (a) host-visible outputs,
-    # (b) device outputs, (c) host-visible with the device batch pass switched off (the general host path of rounds 1-2).
+    # trainer's DataLoader produces every step.  Disjoint sets of such batches, each batch timed once: (a) host-visible outputs and
+    # (b) device outputs through the device batch pass, (c) / (d) the same with the pass switched off (the general host path of rounds 1-2).
     rng = np.random.default_rng(0)
     n_per = int(ptr[1] - ptr[0])
     cols_per = ei.shape[1] // G
@@ -769,14 +769,16 @@ def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
 
     nsh = min(reps, 20)
     sets = [make_shuffled(nsh) for _ in range(3)]
-    time_shuffled(make_shuffled(3))                          # steady state: the graphs' root records are in the device arena, the plan cache is turning over
-    time_shuffled(make_shuffled(3), device=dev)
-    dt_shuf = time_shuffled(sets[0])
-    dt_shuf_dev = time_shuffled(sets[1], device=dev)
-    os.environ["UGS_DEVICE_BATCH"] = "0"
+    os.environ["UGS_DEVICE_BATCH"] = "1"                     # (a), (b): through the device batch pass whatever the batch's size (default: from 2048 columns on)
     try:
+        time_shuffled(make_shuffled(3))                      # steady state: the graphs' root records are in the device arena, the plan cache is turning over
+        time_shuffled(make_shuffled(3), device=dev)
+        dt_shuf = time_shuffled(sets[0])
+        dt_shuf_dev = time_shuffled(sets[1], device=dev)
+        os.environ["UGS_DEVICE_BATCH"] = "0"                 # (c), (d): the general host path
         time_shuffled(make_shuffled(3))
         dt_shuf_host = time_shuffled(sets[2])
+        dt_shuf_host_dev = time_shuffled(make_shuffled(nsh), device=dev)
     finally:
         os.environ.pop("UGS_DEVICE_BATCH", None)
     del sets
@@ -792,7 +794,8 @@ def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
            "hip_graph_replay_ms": round(dt_graph * 1e3, 4) if dt_graph else None, "hip_graph_replay": graph_stats,
            "drop_in_call_subgraphs_per_s": round(rows / dt_host, 1), "drop_in_call_ms": round(dt_host * 1e3, 4),
            "drop_in_call_shuffled_batch_ms": round(dt_shuf * 1e3, 4), "drop_in_call_shuffled_batch_device_out_ms": round(dt_shuf_dev * 1e3, 4),
-           "drop_in_call_shuffled_batch_general_path_ms": round(dt_shuf_host * 1e3, 4), "drop_in_call_device_out_ms": round(dt_devout * 1e3, 4),
+           "drop_in_call_shuffled_batch_general_path_ms": round(dt_shuf_host * 1e3, 4),
+           "drop_in_call_shuffled_batch_general_path_device_out_ms": round(dt_shuf_host_dev * 1e3, 4), "drop_in_call_device_out_ms": round(dt_devout * 1e3, 4),
            "roofline": roofline}
     try:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

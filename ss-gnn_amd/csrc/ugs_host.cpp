@@ -1051,11 +1051,11 @@ int graph_dev_roots(Graph &g, int dev, RootArena *ar, hipStream_t s, Graph::DevR
 }
 
 // UGS_DEVICE_BATCH: 0 = never, 1 = whenever applicable, unset = whenever applicable and the batch has at least
-// kBatchPassMinCols columns.  The chain upload -> kernel -> keys back costs ~25 us of latencies whatever the size; around 1200
-// columns (MUTAG- / QM9-shaped batches of 32 graphs) that equals the host's own pass + plan assembly (0.138 against 0.138 ms and
-// 0.717 against 0.717 ms per call), at 4672 columns (PROTEINS-shaped) the pass wins (0.279 against 0.298 ms host-visible, 0.195
-// against 0.203 ms with device outputs); below ~1000 columns the host is faster.
-constexpr int64_t kBatchPassMinCols = 1024;
+// kBatchPassMinCols columns.  The chain upload -> kernel -> keys back costs ~25 us of latencies whatever the size.  Around 1200
+// columns (MUTAG- / QM9-shaped batches of 32 graphs) that is a tie with the host's own pass + plan assembly for host-visible
+// outputs (0.15 against 0.145 ms, 0.73 against 0.715 ms per call) and 20 us behind it with device outputs (0.195 against 0.175 ms);
+// at 4672 columns (PROTEINS-shaped) the pass wins both (0.276 against 0.31 ms, 0.19 against 0.22 ms).
+constexpr int64_t kBatchPassMinCols = 2048;
 int device_batch_mode() {
     const char *e = std::getenv("UGS_DEVICE_BATCH");
     if (e && e[0] == '0') return 0;

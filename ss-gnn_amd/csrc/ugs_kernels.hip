@@ -743,6 +743,8 @@ constexpr int nst_of(int cap) { return cap <= 64 ? 3 : (cap <= 512 ? 5 : (cap <=
 // The 1408-candidate tier likewise keeps the 1109 words its largest materialising stage needs and runs its final stage (2357 + 1
 // slots) in three passes: 23.2 KB per walk instead of 38.9 KB, 6 walks per CU instead of 4.
 constexpr int tier_index(int cap) { return cap <= 64 ? 0 : (cap <= 512 ? 1 : (cap <= 704 ? 2 : (cap <= 1024 ? 3 : (cap <= 1408 ? 4 : 5)))); }
+// (The same diet for the 1024-candidate tier -- 17.2 KB, 9 walks per CU instead of 8 -- measured slower: 50.9 against 52.0 M/s on
+// degree 160, k = 6: one more resident walk does not pay for the second pass of every final stage above 541 candidates.)
 constexpr int tbl_words(int cap) { constexpr int w[6] = {127, 541, 555, 1109, 1109, 2357}; return (w[tier_index(cap)] + 3) & ~3; }
 
 template <int STAGE> struct ChainAt {
