@@ -394,7 +394,7 @@ int ugs_internal_ctx(int *device, hipStream_t *stream) {
 namespace {
 
 // grow-only device scratch pool (per process): avoids hipMalloc/hipFree on every call
-struct PoolBuf { void *p = nullptr; size_t bytes = 0; int dev = -1; };
+struct PoolBuf { void *p = nullptr; size_t bytes = 0; int dev = -1; bool owned = true; /* false: a piece of a slab, never hipFree'd on its own */ };
 std::mutex g_pool_mu;
 std::vector<PoolBuf> &g_pool_free = *new std::vector<PoolBuf>();
 int pool_get(size_t bytes, int dev, PoolBuf &out) {
@@ -411,17 +411,32 @@ int pool_get(size_t bytes, int dev, PoolBuf &out) {
             return UGS_OK;
         }
     }
+    // Small requests (the plan of a mini-batch, per-call scratch) come in a slab of 16 one-megabyte pieces: a fresh hipMalloc per new plan
+    // costs tens of microseconds -- up to 0.1 ms with a multi-gigabyte plan resident -- and the plan cache hands buffers back only once
+    // its 64 slots are full, so without this the first 64 new mini-batches of a process each pay it.
+    if (bytes <= ((size_t)1 << 20)) {
+        const size_t piece = bytes <= ((size_t)64 << 10) ? (size_t)64 << 10 : (size_t)1 << 20;    // two classes: counters and lists / plans
+        const int n = piece == ((size_t)1 << 20) ? 16 : 64;
+        void *slab = nullptr;
+        if (hipMalloc(&slab, (size_t)n * piece) == hipSuccess) {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            for (int i = 1; i < n; ++i) g_pool_free.push_back(PoolBuf{static_cast<char *>(slab) + (size_t)i * piece, piece, dev, false});
+            out.p = slab; out.bytes = piece; out.dev = dev; out.owned = false;       // (the slab itself is never freed: 4 or 16 MB)
+            return UGS_OK;
+        }
+        (void)hipGetLastError();
+    }
     size_t rounded = (bytes + (bytes >> 2) + 4095) & ~(size_t)4095;
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, rounded);
     if (e != hipSuccess) {   // drop the pool and retry once
         std::vector<PoolBuf> victims;
         { std::lock_guard<std::mutex> lk(g_pool_mu); victims.swap(g_pool_free); }
-        for (auto &b : victims) (void)hipFree(b.p);
+        for (auto &b : victims) if (b.owned) (void)hipFree(b.p);      // (pieces of a slab are dropped, their slab stays)
         e = hipMalloc(&p, rounded);
         if (e != hipSuccess) return fail_hip(e, "hipMalloc");
     }
-    out.p = p; out.bytes = rounded; out.dev = dev;
+    out.p = p; out.bytes = rounded; out.dev = dev; out.owned = true;
     return UGS_OK;
 }
 void pool_put(PoolBuf &b) {
