@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 HERE=$ROOT/ss-gnn_amd/csrc
 W=/tmp/vb/$NAME; mkdir -p $W $ROOT/ab
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -x hip"
-/opt/rocm/bin/hipcc $FL -mllvm -amdgpu-sched-strategy=max-ilp "$@" -c $HERE/ugs_kernels.hip -o $W/ugs_kernels.o &
+/opt/rocm/bin/hipcc $FL -mllvm -amdgpu-sched-strategy=${SCHED:-max-ilp} "$@" -c $HERE/ugs_kernels.hip -o $W/ugs_kernels.o &
 /opt/rocm/bin/hipcc $FL "$@" -c $HERE/ugs_host.cpp -o $W/ugs_host.o &
 wait
 for f in ugs_eps ugs_preproc ugs_apx ugs_apx_gpu ugs_collate ugs_batch; do [ -f $HERE/$f.o ] || { echo "missing $HERE/$f.o (run build.py)"; exit 1; }; done
