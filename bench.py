@@ -298,7 +298,7 @@ class Job:
             self.main.wait_stream(st)
         return res
 
-    def local_ms_per_step(self, steps=16):
+    def local_ms_per_step(self, steps=48):
         """calibration: this rank's OWN work per step in steady state (sampling; pack; on the destination the unpack of a whole
         batch beside the next step's sampling) with no exchange, so that no rank's time contains another rank's"""
         torch = self.torch

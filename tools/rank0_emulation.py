@@ -116,13 +116,13 @@ out["best"] = best
 for share in (80, 100):
     rows0, rounds = equal, []
     for _ in range(3):
-        d_ms, d_rows = run(share, rows0, 0, steps=16)
-        o_ms, o_rows = run(100, rows0, 1, steps=16)
+        d_ms, d_rows = run(share, rows0, 0, steps=48)
+        o_ms, o_rows = run(100, rows0, 1, steps=48)
         rounds.append({"rank0_rows": d_rows, "rank0_ms": d_ms, "other_rows": o_rows, "other_ms": o_ms})
         w0, w1 = d_rows / d_ms, o_rows / o_ms
         rows0 = int(total * w0 / (w0 + (WORLD - 1) * w1))
-    d_ms, d_rows = run(share, rows0, 0)
-    o_ms, o_rows = run(100, rows0, 1)
+    d_ms, d_rows = run(share, rows0, 0, steps=96)
+    o_ms, o_rows = run(100, rows0, 1, steps=96)
     d1, _ = run(share, rows0, 0, nstreams=1)
     o1, _ = run(100, rows0, 1, nstreams=1)
     out[f"auto_split_share{share}"] = {"calibration_rounds": rounds, "rank0_rows": d_rows, "rank0_ms": d_ms, "other_rows": o_rows, "other_ms": o_ms,
