@@ -771,10 +771,29 @@ void hash_words(const int64_t *p, int64_t n, Hash128 &h) {
     for (; i < n; ++i) { a0 = mum((uint64_t)p[i] ^ K0, a0 ^ K2); b0 = mum((uint64_t)p[i] ^ K1, b0 ^ K3); }
     h.a = mum(a0 ^ K1, a1 ^ (uint64_t)n); h.b = mum(b0 ^ K0, b1 ^ (uint64_t)n);
 }
+// Equality of two batches is decided by their 128-bit content hash -- probabilistic, and the multiply-fold lanes are not
+// collision-resistant against crafted input -- plus a WITNESS of 32 words read back from fixed places of the batch (first, last and
+// evenly strided columns of both rows and the ends of ptr): a false match would need a hash collision between two batches that also
+// agree in those words.
+struct Witness {
+    int64_t w[32];
+    bool operator==(const Witness &o) const { return std::memcmp(w, o.w, sizeof(w)) == 0; }
+};
+Witness batch_witness(const int64_t *src, const int64_t *dst, int64_t E, const int64_t *ptr, int64_t G) {
+    Witness x{};
+    for (int i = 0; i < 14; ++i) {
+        const int64_t j = E > 0 ? (int64_t)((__int128)i * (E - 1) / 13) : 0;
+        x.w[i] = E > 0 ? src[j] : 0;
+        x.w[14 + i] = E > 0 ? dst[j] : 0;
+    }
+    x.w[28] = ptr[0]; x.w[29] = ptr[G]; x.w[30] = ptr[G / 2]; x.w[31] = E ^ (G << 40);
+    return x;
+}
 struct BatchEntry {
     Hash128 h; int64_t E, G; int k, dev;
     uint64_t plan_key;
     std::vector<std::pair<uint64_t, int64_t>> graphs;     // (LRU key, handle) of every non-degenerate graph, in graph order
+    Witness wit;
 };
 std::mutex g_bi_mu;
 std::list<BatchEntry> &g_batch_index = *new std::list<BatchEntry>();   // front = most recent, at most as many as cached plans
@@ -1373,14 +1392,16 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
     // the batch as a whole: seen before, and everything it needs still cached?
     const bool use_index = std::getenv("UGS_NO_BATCH_INDEX") == nullptr;
     Hash128 bh{0, 0};
+    Witness wit{};
     if (use_index) {
         bh = batch_hash(src, dst, E, ptr, G);
+        wit = batch_witness(src, dst, E, ptr, G);
         BatchEntry found;
         bool have = false;
         {
             std::lock_guard<std::mutex> lk(g_bi_mu);
             for (auto it = g_batch_index.begin(); it != g_batch_index.end(); ++it)
-                if (it->h == bh && it->E == E && it->G == G && it->k == k && it->dev == dc.id) {
+                if (it->h == bh && it->E == E && it->G == G && it->k == k && it->dev == dc.id && it->wit == wit) {
                     g_batch_index.splice(g_batch_index.begin(), g_batch_index, it);
                     found = *it; have = true;
                     break;
@@ -1414,7 +1435,7 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
                 std::lock_guard<std::mutex> lk(g_bi_mu);
                 for (auto it = g_batch_index.begin(); it != g_batch_index.end(); ++it)
                     if (it->h == bh && it->E == E && it->G == G && it->k == k && it->dev == dc.id) { g_batch_index.erase(it); break; }
-                g_batch_index.push_front(BatchEntry{bh, E, G, k, dc.id, dp->cache_key, std::move(touched_d)});
+                g_batch_index.push_front(BatchEntry{bh, E, G, k, dc.id, dp->cache_key, std::move(touched_d), wit});
                 while (g_batch_index.size() > g_plan_cache_cap) g_batch_index.pop_back();
             }
             *plan_out = dp;
@@ -1479,7 +1500,7 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
         std::lock_guard<std::mutex> lk(g_bi_mu);
         for (auto it = g_batch_index.begin(); it != g_batch_index.end(); ++it)
             if (it->h == bh && it->E == E && it->G == G && it->k == k && it->dev == dc.id) { g_batch_index.erase(it); break; }
-        g_batch_index.push_front(BatchEntry{bh, E, G, k, dc.id, pkey, std::move(touched)});
+        g_batch_index.push_front(BatchEntry{bh, E, G, k, dc.id, pkey, std::move(touched), wit});
         while (g_batch_index.size() > g_plan_cache_cap) g_batch_index.pop_back();
     };
     if (ugs_plan *cached = plan_cache_get(pkey, dc.id)) { remember(); *plan_out = cached; return UGS_OK; }
