@@ -22,6 +22,7 @@
 // graph of at most 1000 columns (cache.hpp:100 samples longer ones), so a cached graph with the same key HAS this CSR; graphs
 // beyond the limits below send the whole batch down the host path.
 #include "ugs_device.h"
+#include <cstdlib>
 
 namespace {
 
@@ -275,6 +276,11 @@ __global__ __launch_bounds__(kBpBlock) void ugs_bp_build(BpBuild a) {
 
 }  // namespace
 
+int64_t ugs_batch_pass_fused_work() {
+    if (const char *e = std::getenv("UGS_BP_FUSED_WORK")) return std::atoll(e);
+    return UGS_BATCH_PASS_FUSED_WORK;
+}
+
 hipError_t ugs_launch_batch_pass(const int64_t *d_src, const int64_t *d_dst, int64_t E, const int64_t *d_ptr, int64_t G, int k,
                                  int32_t *d_owner, uint32_t *d_cnt_jminc_jmax /* [3G], two-kernel variant only */, const int64_t *d_rstart,
                                  int64_t *d_rowptr, int2 *d_adj, int2 *d_adjf, unsigned long long *d_bump, unsigned long long bump_base,
@@ -285,7 +291,7 @@ hipError_t ugs_launch_batch_pass(const int64_t *d_src, const int64_t *d_dst, int
     a.bump = d_bump; a.bump_base = bump_base; a.epoch = epoch;
     a.h_keys = static_cast<unsigned long long *>(h_back);
     a.h_cnt = reinterpret_cast<uint32_t *>(a.h_keys + G); a.h_jminc = a.h_cnt + G; a.h_jmax = a.h_jminc + G; a.h_flag = a.h_jmax + G;
-    if (G * E <= UGS_BATCH_PASS_FUSED_WORK) {              // every block scans every column: no assign launch, no memset, no atomics
+    if (G * E <= ugs_batch_pass_fused_work()) {            // every block scans every column: no assign launch, no memset, no atomics
         hipLaunchKernelGGL(ugs_bp_build<true>, dim3((unsigned)G), dim3(kBpBlock), 0, s, a);
         return hipGetLastError();
     }

@@ -143,6 +143,7 @@ hipError_t ugs_launch_collate_unpack(const void *d_msgs, int world, int64_t msg_
 #define UGS_BATCH_PASS_MAX_COLS 1000   /* a key covers every column up to here (reference include/cache.hpp:100 samples longer graphs) */
 #define UGS_BATCH_PASS_MAX_N 2048
 #define UGS_BATCH_PASS_FUSED_WORK (4ll << 20)   /* G * E up to here: the build kernel slices the batch itself (one launch) */
+int64_t ugs_batch_pass_fused_work();             /* the limit in force: UGS_BP_FUSED_WORK overrides it (testing aid: 0 = always two kernels) */
 hipError_t ugs_launch_batch_pass(const int64_t *d_src, const int64_t *d_dst, int64_t E, const int64_t *d_ptr, int64_t G, int k,
                                  int32_t *d_owner, uint32_t *d_cnt_jminc_jmax, const int64_t *d_rstart, int64_t *d_rowptr, int2 *d_adj,
                                  int2 *d_adjf, unsigned long long *d_bump, unsigned long long bump_base, uint32_t epoch, void *h_back,

@@ -1136,7 +1136,7 @@ int device_batch_plan(const int64_t *src, const int64_t *dst, int64_t E, const i
     auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + std::max<size_t>(bytes, 8)); return o; };
     const size_t o_desc = take(desc_bytes), o_row = take((size_t)rows_total * sizeof(int64_t));
     const size_t o_adj = take((size_t)2 * E * sizeof(int2)), o_adjf = take((size_t)2 * E * sizeof(int2));
-    const bool fused = G * E <= UGS_BATCH_PASS_FUSED_WORK;
+    const bool fused = G * E <= ugs_batch_pass_fused_work();
     const size_t o_up = take(up_words * 8), o_owner = take(fused ? 8 : (size_t)E * 4), o_cnt = take(fused ? 8 : (size_t)G * 12);
     auto *p = new ugs_plan();
     if (int rc = pool_get(off, dc.id, p->blob_buf)) { delete p; return rc; }
