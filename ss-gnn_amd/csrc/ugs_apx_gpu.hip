@@ -17,6 +17,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 namespace {
 
 constexpr int kMaxK = 32;                       // the product's k limit (UGS_KMAX); (k-1)! permutations per trial are capped at 720 like the reference (:370)
@@ -184,15 +186,6 @@ struct CounterRng {           // host generator of the APX-DD order: one draw pe
     }
 };
 
-void cut_params(int k, double alpha, double beta, double delta, int &h, double &ell) {      // reference :184-196
-    const double ell_raw = 1.0 / (k * delta * alpha * alpha);
-    const double hd = ell_raw * ell_raw * std::log(k / beta);
-    if (std::isinf(hd) || hd > 100) h = 100;
-    else if (hd < 10.0) h = 10;
-    else h = static_cast<int>(std::ceil(hd));
-    ell = std::min(ell_raw, static_cast<double>(h) * 0.5);
-}
-
 }  // namespace
 
 int ugs_internal_fail(int code, const char *msg);      // ugs_host.cpp: sets the message ugs_last_error() returns
@@ -211,11 +204,11 @@ extern "C" int ugs_apx_gpu_sample_batch(const int64_t *edge_index, int64_t row_s
     hipStream_t st = nullptr;
     if (int rc = ugs_internal_ctx(&dev_id, &st)) return rc;          // the thread's device (ugs_set_device) and stream, like every other entry point
     const int64_t c0 = std::max<int64_t>(ptr[0], 0), c1 = std::min<int64_t>(ptr[1], num_cols);
-    const SimpleGraph g = read_graph(edge_index, edge_index + row_stride, c0, c1);
+    const Csr g = csr_of_columns(edge_index, edge_index + row_stride, c0, c1);
     if (g.n < k || m_per_graph <= 0) return UGS_OK;
     CounterRng ors(seed ^ 0xa0761d6478bd642full);
     const double beta = epsilon / 2.0;
-    const Order o = dominating_order(g, k, beta, ors);
+    const Ranking o = rank_vertices(g, k, beta, ors);
     if (order_pos_out && est_out && order_capacity >= g.n)
         for (int v = 0; v < g.n; ++v) { order_pos_out[v] = o.pos[(size_t)v]; est_out[v] = o.est[(size_t)v]; }
     std::vector<double> cum((size_t)g.n);
@@ -228,8 +221,8 @@ extern "C" int ugs_apx_gpu_sample_batch(const int64_t *edge_index, int64_t row_s
     const double gamma = epsilon * std::pow(3.0, -k) * std::pow(k, static_cast<double>(-C2));
     const double rho = gamma;
     ApxParams P{};
-    cut_params(k, alpha, beta, gamma / std::pow(k, 4.0), P.h_grow, P.ell_grow);
-    cut_params(k, alpha, beta / std::pow(k, 6.0), rho / (k * k), P.h_prob, P.ell_prob);
+    const CutBudget bg = cut_budget(k, alpha, beta, gamma / std::pow(k, 4.0)), bp = cut_budget(k, alpha, beta / std::pow(k, 6.0), rho / (k * k));
+    P.h_grow = bg.draws; P.ell_grow = bg.floor_hits; P.h_prob = bp.draws; P.ell_prob = bp.floor_hits;
     P.n = g.n; P.k = k; P.Z = Z; P.seed = seed;
     P.trial_cap = kTrialCap;
     if (const char *ev = std::getenv("UGS_APX_TRIAL_CAP")) { const long c = std::atol(ev); if (c > 0 && c < (long)kTrialCap) P.trial_cap = (uint32_t)c; }

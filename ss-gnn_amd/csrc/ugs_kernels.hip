@@ -1099,6 +1099,24 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
     for (int step = 0;; ++step) {
         Grp<GS> g = g_;                                                       // see select_lds: keeps lane-derived constants out of long-lived registers
         if constexpr (GS == 64) asm volatile("" : "+v"(g.lane));
+#ifdef UGS_PAD      // diagnostic A/B builds only (tools/pad_probe.sh): 64 dummy instructions per growth step -- scalar or vector, 4- or 8-byte
+        {           // encodings -- to tell instruction-issue, instruction-fetch and vector-pipe limits apart; no output depends on them
+            uint32_t pad_;
+#if UGS_PAD == 1
+#define UGS_PAD1 asm volatile("s_mov_b32 %0, 0" : "=s"(pad_));
+#elif UGS_PAD == 2
+#define UGS_PAD1 asm volatile("s_mov_b32 %0, 0x12345678" : "=s"(pad_));
+#elif UGS_PAD == 3
+#define UGS_PAD1 asm volatile("v_mov_b32_e32 %0, 0" : "=v"(pad_));
+#else
+#define UGS_PAD1 asm volatile("v_mov_b32_e64 %0, 0" : "=v"(pad_));
+#endif
+#define UGS_PAD8 UGS_PAD1 UGS_PAD1 UGS_PAD1 UGS_PAD1 UGS_PAD1 UGS_PAD1 UGS_PAD1 UGS_PAD1
+            UGS_PAD8 UGS_PAD8 UGS_PAD8 UGS_PAD8 UGS_PAD8 UGS_PAD8 UGS_PAD8 UGS_PAD8
+#undef UGS_PAD8
+#undef UGS_PAD1
+        }
+#endif
         bool ok;
         if (step < k - 1) {                                                   // the last vertex adds no candidates
             if constexpr (PAD) ok = scan_prow<SP, true, STG>(ws, g, P, v, root_vi, size, c, hcount, ecount, e0, gd.vbase + v, sc);
