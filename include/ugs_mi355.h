@@ -123,6 +123,13 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
 /* Plan of one preprocessing handle (the handle API's graph). */
 int ugs_plan_create_handle(int64_t handle, ugs_plan **plan_out);
 int ugs_plan_release(ugs_plan *plan);
+/* What the walk kernels read for graph `graph` of a plan, copied back from HBM (parity tests of the preprocessing that runs on the
+ * device, incl. the cold path of the device batch pass: graphs the LRU does not know get their root records from ugs_bp_roots;
+ * the host path's counterpart is ugs_preproc_dump).  level 0: prob / alias / v_self = order[vi] / v_alias = order[alias[vi]] per
+ * order position (reference include/sampler.hpp:44-69 + src/preproc.cpp:176-256); levels 1, 2: the viable list (vi, order[vi])
+ * (src/sampler.cpp:121-150).  Arrays hold `capacity` entries; any pointer may be NULL.  Synchronises with the device. */
+int ugs_plan_graph_roots(ugs_plan *plan, int64_t graph, int64_t capacity, int32_t *level, int32_t *num_nodes, int32_t *num_viable,
+                         double *prob, int32_t *alias, int32_t *v_self, int32_t *v_alias, int32_t *viable_vi, int32_t *viable_v);
 /* A second plan over the same device arrays with private scratch (a plan's scratch serves one stream at a time): two steps in
  * flight on two streams go through a plan and its twin alternately.  Release both; the arrays live until the last one goes. */
 int ugs_plan_twin(ugs_plan *plan, int k, ugs_plan **twin_out);

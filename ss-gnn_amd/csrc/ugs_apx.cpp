@@ -5,7 +5,7 @@
 // (:318-382), rejection loop (:388-455), wrapper (:461-519).  The reference feeds EVERYTHING -- the ranking, every cut estimate of
 // every trial of every sample -- from ONE sequential std::mt19937_64, so a bit-exact result has to consume that stream in the same
 // sequence; that sequence and the floating-point expressions deciding comparisons are the contract, and the golden fixture
-// tests/golden/apx_ugs.json (written by the unmodified reference build, oracle/make_golden_apx.py) holds this file to it.
+// tests/golden/apx_ugs.json (written by the unmodified reference build; generator committed beside the checker) holds this file to it.
 //
 // Everything else is this repo's own form: one `Trials` object owns flat scratch for the whole call (no container is allocated
 // inside a trial); set membership is an epoch stamp per vertex; a cut estimate is a running sum handed back with its terms; the

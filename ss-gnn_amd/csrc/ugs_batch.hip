@@ -77,6 +77,7 @@ struct BpBuild {
     int32_t k;
     int64_t *rowptr;
     int2 *adj, *adjf;
+    int32_t *vrank;              // [rows]: rank of vertex x of graph g at rstart[g] + x (read by ugs_bp_roots for graphs the LRU does not know)
 };
 
 constexpr int kBpMaxCols = UGS_BATCH_PASS_MAX_COLS, kBpMaxN = UGS_BATCH_PASS_MAX_N;
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(kBpBlock) void ugs_bp_build(BpBuild a) {
     //    through a 64-bit member mask per row in LDS (atomic OR, read back) and rank themselves by lane.
     const int64_t abase = (int64_t)cstart_sh, rbase = a.rstart[g];
     for (int x = tid; x <= n; x += kBpBlock) a.rowptr[rbase + x] = abase + (int64_t)RP[x];
+    for (int x = tid; x < n; x += kBpBlock) a.vrank[rbase + x] = (int32_t)RNK[x];
     for (int x = tid; x < n; x += kBpBlock) { CUR[x] = RP[x]; MSK[x] = 0ull; }
     __syncthreads();
     if (wv == 0) {
@@ -274,7 +276,154 @@ __global__ __launch_bounds__(kBpBlock) void ugs_bp_build(BpBuild a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// ugs_bp_roots: the REST of the reference's preprocessing (src/preproc.cpp:142-256 suffix degrees, k-reachability of every root
+// inside its suffix graph, bucket weights max(1, sdeg)^(k-1), Z; include/sampler.hpp:44-69 the Vose alias table) for the graphs
+// of a device-built plan that the LRU did not know -- one 256-thread block per such graph, from the CSR and ranks ugs_bp_build has
+// just written.  The root records (or the viable list of relaxation levels 1 / 2, src/sampler.cpp:121-150) go straight into the
+// device's arena; the host receives 32 bytes per graph (level, list length, Z, degree statistics) and never sees the graph.
+// Floating point: every operation whose result the reference's output depends on is done in the reference's order in IEEE fp64
+// (this file is built with -ffp-contract=off): b by repeated multiplication, Z summed over the order positions ascending,
+// p = b * n / Z, and the alias table by ONE lane -- Vose's loop is sequential by definition (two stacks filled in ascending
+// index, p[l] = (p[l] + p[s]) - 1.0); the lane keeps the top of the `large` stack and its p in registers, so an iteration is
+// two dependent LDS reads.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct BpRoots {
+    const int64_t *ptr, *rstart, *rowptr;
+    const int2 *adj;
+    const int32_t *vrank;
+    const UgsBpMissIn *in;       // pinned host memory, read by the kernel
+    UgsBpMissOut *out;           // pinned host memory, written by the kernel
+    UgsRootRec *roots;
+    int2 *via;
+    int32_t k;
+};
+
+constexpr int kBrMaxN = UGS_BATCH_ROOTS_MAX_N;
+
+__global__ __launch_bounds__(kBpBlock) void ugs_bp_roots(BpRoots a) {
+    __shared__ double P[kBrMaxN];                                  // bucket weight -> scaled weight -> acceptance probability, in place
+    __shared__ uint16_t ORD[kBrMaxN], RNK[kBrMaxN], SDEG[kBrMaxN], ALI[kBrMaxN], LO[kBrMaxN], HI[kBrMaxN];
+    __shared__ uint16_t RP[kBrMaxN + 1], NBR[2 * kBpMaxCols];
+    __shared__ uint16_t LIST[kBpBlock][UGS_KMAX];                  // per thread: the vertices its root has reached
+    __shared__ UgsBpMissIn mi_sh;
+    __shared__ unsigned long long s2_sh;
+    __shared__ uint32_t maxd_sh, nz_sh;
+    __shared__ double z_sh;
+    const int tid = (int)threadIdx.x;
+    if (tid == 0) { mi_sh = a.in[blockIdx.x]; s2_sh = 0ull; maxd_sh = 0u; }
+    __syncthreads();
+    const int g = mi_sh.g, k = a.k;
+    const int n = (int)(a.ptr[g + 1] - a.ptr[g]);
+    const int64_t rb = a.rstart[g], abase = a.rowptr[rb];
+    const int nnz = (int)(a.rowptr[rb + n] - abase);
+    for (int x = tid; x <= n; x += kBpBlock) RP[x] = (uint16_t)(a.rowptr[rb + x] - abase);
+    for (int e = tid; e < nnz; e += kBpBlock) NBR[e] = (uint16_t)a.adj[abase + e].x;
+    for (int x = tid; x < n; x += kBpBlock) { const int r = a.vrank[rb + x]; RNK[x] = (uint16_t)r; ORD[r] = (uint16_t)x; ALI[x] = 0; }
+    __syncthreads();
+    {   // degree statistics for the tier choice (host: order_by_degree): sums of integers, exact in any order
+        unsigned long long s2 = 0ull; uint32_t md = 0u;
+        for (int x = tid; x < n; x += kBpBlock) { const uint32_t d = (uint32_t)RP[x + 1] - (uint32_t)RP[x]; s2 += (unsigned long long)d * d; md = d > md ? d : md; }
+        if (s2) atomicAdd(&s2_sh, s2);
+        if (md) atomicMax(&maxd_sh, md);
+    }
+    // suffix degree, reachability and weight of every order position (host: root_stats_host + weigh_roots)
+    uint16_t *L = LIST[tid];
+    for (int vi = tid; vi < n; vi += kBpBlock) {
+        const int v = ORD[vi];
+        int c = 0;
+        for (int p = RP[v], e = RP[v + 1]; p < e; ++p) c += (int)RNK[NBR[p]] >= vi ? 1 : 0;
+        SDEG[vi] = (uint16_t)c;
+        int cnt = 1;
+        L[0] = (uint16_t)v;
+        for (int h = 0; h < cnt && cnt < k; ++h) {
+            const int u = L[h];
+            for (int p = RP[u], e = RP[u + 1]; p < e && cnt < k; ++p) {
+                const int w = NBR[p];
+                if ((int)RNK[w] < vi) continue;
+                bool seen = false;
+                for (int i = 0; i < cnt; ++i) seen |= (int)L[i] == w;
+                if (!seen) L[cnt++] = (uint16_t)w;
+            }
+        }
+        double b = 0.0;
+        if (cnt >= k) {
+            const double d = (double)(c > 1 ? c : 1);
+            b = 1.0;
+            for (int t = 1; t < k; ++t) b *= d;
+        }
+        P[vi] = b;
+    }
+    __syncthreads();
+    if (tid == 0) {                                                  // Z in order-position order; adding the zeros of unreachable roots changes nothing
+        double z = 0.0; uint32_t nz = 0u;
+        for (int vi = 0; vi < n; ++vi) { const double b = P[vi]; z += b; nz += b > 0.0 ? 1u : 0u; }
+        z_sh = z; nz_sh = nz;
+    }
+    __syncthreads();
+    const double Z = z_sh;
+    const uint32_t nz = nz_sh;
+    int level = 0, n_via = 0;
+    if (Z > 0.0) {
+        for (int i = tid; i < n; i += kBpBlock) P[i] = P[i] * n / Z;
+        __syncthreads();
+        if (tid == 0) {
+            int nl = 0, nh = 0;
+            for (int i = 0; i < n; ++i) { if (P[i] < 1.0) LO[nl++] = (uint16_t)i; else HI[nh++] = (uint16_t)i; }
+            if (nl > 0 && nh > 0) {
+                int l = HI[nh - 1];
+                double pl = P[l];
+                while (nl > 0 && nh > 0) {
+                    const int s = LO[--nl];
+                    const double ps = P[s];
+                    ALI[s] = (uint16_t)l;
+                    pl = (pl + ps) - 1.0;
+                    if (pl < 1.0) {
+                        P[l] = pl;
+                        --nh;
+                        LO[nl++] = (uint16_t)l;
+                        if (nh > 0) { l = HI[nh - 1]; pl = P[l]; }
+                    }
+                }
+            }
+            for (int i = 0; i < nh; ++i) P[HI[i]] = 1.0;              // leftovers of either stack accept with probability 1
+            for (int i = 0; i < nl; ++i) P[LO[i]] = 1.0;
+        }
+        __syncthreads();
+    }
+    if (nz > 0u) {
+        UgsRootRec *rec = a.roots + mi_sh.roots_off;
+        for (int vi = tid; vi < n; vi += kBpBlock) {
+            UgsRootRec r;
+            r.prob = P[vi]; r.alias = (int32_t)ALI[vi]; r.v_self = (int32_t)ORD[vi]; r.v_alias = (int32_t)ORD[ALI[vi]]; r.pad = 0;
+            rec[vi] = r;
+        }
+    } else if (tid == 0) {                                           // relaxed root draw: the roots with a suffix neighbour, else all of them
+        int2 *via = a.via + mi_sh.via_off;
+        level = 1;
+        for (int vi = 0; vi < n; ++vi) if (SDEG[vi] > 0) via[n_via++] = make_int2(vi, (int)ORD[vi]);
+        if (n_via == 0) { level = 2; for (int vi = 0; vi < n; ++vi) via[n_via++] = make_int2(vi, (int)ORD[vi]); }
+    }
+    if (tid == 0) {
+        UgsBpMissOut o;
+        o.level = level; o.n_viable = n_via; o.nonzero = (int32_t)nz; o.max_deg = (int32_t)maxd_sh;
+        o.Z = Z;
+        o.sb_deg = nnz > 0 ? (double)s2_sh / (double)nnz : 0.0;
+        a.out[blockIdx.x] = o;
+    }
+}
+
 }  // namespace
+
+hipError_t ugs_launch_batch_roots(const int64_t *d_ptr, const int64_t *d_rstart, const int64_t *d_rowptr, const int2 *d_adj, const int32_t *d_vrank,
+                                  const UgsBpMissIn *h_in, UgsBpMissOut *h_out, int64_t misses, int k, UgsRootRec *d_roots, int2 *d_via, hipStream_t s) {
+    if (misses <= 0) return hipSuccess;
+    BpRoots a{};
+    a.ptr = d_ptr; a.rstart = d_rstart; a.rowptr = d_rowptr; a.adj = d_adj; a.vrank = d_vrank; a.in = h_in; a.out = h_out;
+    a.roots = d_roots; a.via = d_via; a.k = k;
+    hipLaunchKernelGGL(ugs_bp_roots, dim3((unsigned)misses), dim3(kBpBlock), 0, s, a);
+    return hipGetLastError();
+}
 
 int64_t ugs_batch_pass_fused_work() {
     if (const char *e = std::getenv("UGS_BP_FUSED_WORK")) return std::atoll(e);
@@ -283,11 +432,12 @@ int64_t ugs_batch_pass_fused_work() {
 
 hipError_t ugs_launch_batch_pass(const int64_t *d_src, const int64_t *d_dst, int64_t E, const int64_t *d_ptr, int64_t G, int k,
                                  int32_t *d_owner, uint32_t *d_cnt_jminc_jmax /* [3G], two-kernel variant only */, const int64_t *d_rstart,
-                                 int64_t *d_rowptr, int2 *d_adj, int2 *d_adjf, unsigned long long *d_bump, unsigned long long bump_base,
+                                 int64_t *d_rowptr, int2 *d_adj, int2 *d_adjf, int32_t *d_vrank, unsigned long long *d_bump, unsigned long long bump_base,
                                  uint32_t epoch, void *h_back /* pinned: keys[G] u64 | cnt[G] | jminc[G] | jmax[G] | flag */, hipStream_t s) {
     if (G <= 0) return hipSuccess;
     BpBuild a{};
     a.src = d_src; a.dst = d_dst; a.ptr = d_ptr; a.G = G; a.E = E; a.rstart = d_rstart; a.k = k; a.rowptr = d_rowptr; a.adj = d_adj; a.adjf = d_adjf;
+    a.vrank = d_vrank;
     a.bump = d_bump; a.bump_base = bump_base; a.epoch = epoch;
     a.h_keys = static_cast<unsigned long long *>(h_back);
     a.h_cnt = reinterpret_cast<uint32_t *>(a.h_keys + G); a.h_jminc = a.h_cnt + G; a.h_jmax = a.h_jminc + G; a.h_flag = a.h_jmax + G;

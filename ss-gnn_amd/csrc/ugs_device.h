@@ -146,8 +146,14 @@ hipError_t ugs_launch_collate_unpack(const void *d_msgs, int world, int64_t msg_
 int64_t ugs_batch_pass_fused_work();             /* the limit in force: UGS_BP_FUSED_WORK overrides it (testing aid: 0 = always two kernels) */
 hipError_t ugs_launch_batch_pass(const int64_t *d_src, const int64_t *d_dst, int64_t E, const int64_t *d_ptr, int64_t G, int k,
                                  int32_t *d_owner, uint32_t *d_cnt_jminc_jmax, const int64_t *d_rstart, int64_t *d_rowptr, int2 *d_adj,
-                                 int2 *d_adjf, unsigned long long *d_bump, unsigned long long bump_base, uint32_t epoch, void *h_back,
+                                 int2 *d_adjf, int32_t *d_vrank, unsigned long long *d_bump, unsigned long long bump_base, uint32_t epoch, void *h_back,
                                  hipStream_t s);
+// graphs of a device-built plan the LRU does not know (cold path): the rest of their preprocessing on the device (ugs_bp_roots)
+#define UGS_BATCH_ROOTS_MAX_N 1024     /* larger unknown graphs are preprocessed on the host, as before */
+struct UgsBpMissIn { int32_t g; int32_t pad; int64_t roots_off; int64_t via_off; };           // arena offsets (elements) reserved by the host
+struct UgsBpMissOut { int32_t level, n_viable, nonzero, max_deg; double Z, sb_deg; };
+hipError_t ugs_launch_batch_roots(const int64_t *d_ptr, const int64_t *d_rstart, const int64_t *d_rowptr, const int2 *d_adj, const int32_t *d_vrank,
+                                  const UgsBpMissIn *h_in, UgsBpMissOut *h_out, int64_t misses, int k, UgsRootRec *d_roots, int2 *d_via, hipStream_t s);
 hipError_t ugs_launch_scan(const uint32_t *counts, int64_t rows, int64_t *edge_ptr, int64_t *block_tmp, hipStream_t s);
 hipError_t ugs_launch_fill(const UgsFillArgs &a, int wide, int device_cus, hipStream_t s, UgsLaunchInfo *info);
 int64_t ugs_scan_tmp_words(int64_t rows);

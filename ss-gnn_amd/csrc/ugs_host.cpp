@@ -85,6 +85,13 @@ struct Graph {
     int nonzero = 0;
     int level = 0;                    // relaxation level of the root draw
     std::vector<int32_t> viable;      // order positions for levels 1, 2
+    int64_t n_viable = 0;             // their number (a graph preprocessed by the device batch pass has only this)
+    // A graph the device batch pass preprocessed (cold path, ugs_bp_roots) exists on the host as a STUB: n, nnz, level, Z, the degree
+    // statistics and its root records in a device's arena -- no arrays.  The general path, which has the graph's columns at hand
+    // whenever it meets the graph, fills the arrays in then (complete_on_host).
+    bool host_ready = true;
+    std::vector<int64_t> stub_cols;   // stub: its span of the batch's columns, sources then targets (global ids), and
+    int64_t stub_lo = 0;              //       the batch's node offset of the graph -- what completion needs, dropped afterwards
     int64_t max_deg = 0;
     double sb_deg = 0.0;              // size-biased mean CSR degree (sum d^2 / sum d)
     std::mutex plan_mu;
@@ -241,7 +248,28 @@ void weigh_roots(Graph &G, int k) {
         for (int vi = 0; vi < n; ++vi) if (G.sdeg[(size_t)vi] > 0) G.viable.push_back(vi);
         if (G.viable.empty()) { G.level = 2; for (int vi = 0; vi < n; ++vi) G.viable.push_back(vi); }
     }
+    G.n_viable = (int64_t)G.viable.size();
     if (debug_on()) std::fprintf(stderr, "[UGS PREPROC] n=%d k=%d Z=%.2e viable=%d/%d\n", n, k, G.Z, G.nonzero, n);
+}
+
+// arrays of a stub (see Graph::host_ready) from the graph's columns, with the k it was preprocessed for: the same values the
+// device computed (both equal the reference's), now on the host as well
+void complete_on_host(Graph &G) {
+    std::lock_guard<std::mutex> lk(G.pre_mu);
+    if (G.host_ready) return;
+    const size_t span = G.stub_cols.size() / 2;
+    std::vector<int64_t> ru, rv;
+    ru.reserve(span); rv.reserve(span);
+    for (size_t j = 0; j < span; ++j) {                                  // the graph's columns: both endpoints inside its node range
+        const int64_t u = G.stub_cols[j] - G.stub_lo, v = G.stub_cols[span + j] - G.stub_lo;
+        if ((uint64_t)u < (uint64_t)G.n && (uint64_t)v < (uint64_t)G.n) { ru.push_back(u); rv.push_back(v); }
+    }
+    build_adjacency(G, ru.data(), rv.data(), (int64_t)ru.size());
+    order_by_degree(G);
+    root_stats_host(G, G.k_built);
+    weigh_roots(G, G.k_built);
+    std::vector<int64_t>().swap(G.stub_cols);
+    G.host_ready = true;
 }
 
 int preprocess_on_device(Graph &G, const int64_t *src, const int64_t *dst, int64_t E, int k, bool &done);   // below, after the device helpers
@@ -326,6 +354,12 @@ struct Lru {
         items.emplace_front(key, val);
         index[key] = items.begin();
         return ev;
+    }
+    void erase(uint64_t key) {
+        auto it = index.find(key);
+        if (it == index.end()) return;
+        items.erase(it->second);
+        index.erase(it);
     }
 };
 std::mutex g_lru_mu;
@@ -933,6 +967,7 @@ int ensure_prow(ugs_plan *plan, hipStream_t s) {
     while (shift < 6 && (double)((1 << shift) - 1) < sb + 3.0 * std::sqrt(sb) + 1.0) ++shift;
     if (const char *e = std::getenv("UGS_PROW_SHIFT")) { const int f = std::atoi(e); if (f >= 3 && f <= 6) shift = f; }
     const size_t bytes = ((size_t)plan->nverts << shift) * sizeof(int2);
+    if (bytes >= ((size_t)1 << 32)) { plan->prow_failed = true; return UGS_OK; }       // the walk kernels address a block by a 32-bit byte offset
     if (bytes <= ((size_t)64 << 20)) {
         const std::string keep = t_err;
         if (pool_get(bytes, plan->device, plan->prow) != UGS_OK) { t_err = keep; plan->prow_failed = true; return UGS_OK; }
@@ -1053,6 +1088,7 @@ void arena_release(int dev, int64_t roots_off, int64_t n_roots, int64_t via_off,
 int graph_dev_roots(Graph &g, int dev, RootArena *ar, hipStream_t s, Graph::DevRoots &out) {
     std::lock_guard<std::mutex> lk(g.pre_mu);
     for (auto &d : g.dev_roots) if (d.dev == dev) { out = d; return UGS_OK; }
+    if (!g.host_ready) return UGS_E_UNSUPPORTED;                        // a stub of another device's pass: the general path completes it first
     Graph::DevRoots d{dev, -1, 0, -1, 0};
     if (g.level == 0) d.n_roots = g.n; else d.n_via = (int64_t)g.viable.size();
     {
@@ -1111,7 +1147,12 @@ int device_batch_plan(const int64_t *src, const int64_t *dst, int64_t E, const i
     // pinned staging, one buffer: [src E | dst E | ptr G+1 | rstart G] goes up in ONE copy, [keys G | cnt G | jminc G | jmax G | flag] comes
     // back in one, two descriptor slots go up behind the LRU replay
     const size_t up_words = (size_t)(2 * E + 2 * G + 1), back_bytes = (size_t)G * 20 + 8, desc_bytes = (size_t)G * sizeof(UgsGraphDesc);
-    const size_t st_back = align_up(up_words * 8), st_desc = align_up(st_back + back_bytes), st_total = align_up(st_desc + 2 * align_up(desc_bytes));
+    const size_t miss_bytes = (size_t)G * (sizeof(UgsBpMissIn) + sizeof(UgsBpMissOut));
+    const size_t st_back = align_up(up_words * 8), st_desc = align_up(st_back + back_bytes), st_miss = align_up(st_desc + 2 * align_up(desc_bytes)),
+                 st_total = align_up(st_miss + miss_bytes);
+    // the staging's layout depends on this call's E and G: a descriptor copy of an earlier call (asynchronous, from a region placed by
+    // ITS sizes) must be over before anything here is written.  Normally long done.
+    for (auto &ev : ar->desc_ev) if (ev) (void)hipEventSynchronize(ev);
     if (ar->pinned_bytes < st_total) {
         if (ar->pinned) { for (auto &ev : ar->desc_ev) if (ev) (void)hipEventSynchronize(ev); (void)hipHostFree(ar->pinned); }
         ar->pinned = nullptr; ar->pinned_bytes = 0;
@@ -1137,6 +1178,7 @@ int device_batch_plan(const int64_t *src, const int64_t *dst, int64_t E, const i
     const size_t o_desc = take(desc_bytes), o_row = take((size_t)rows_total * sizeof(int64_t));
     const size_t o_adj = take((size_t)2 * E * sizeof(int2)), o_adjf = take((size_t)2 * E * sizeof(int2));
     const bool fused = G * E <= ugs_batch_pass_fused_work();
+    const size_t o_vrank = take((size_t)rows_total * sizeof(int32_t));
     const size_t o_up = take(up_words * 8), o_owner = take(fused ? 8 : (size_t)E * 4), o_cnt = take(fused ? 8 : (size_t)G * 12);
     auto *p = new ugs_plan();
     if (int rc = pool_get(off, dc.id, p->blob_buf)) { delete p; return rc; }
@@ -1153,7 +1195,8 @@ int device_batch_plan(const int64_t *src, const int64_t *dst, int64_t E, const i
     hipError_t e = hipMemcpyAsync(d_src, hostv, up_words * 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = ugs_launch_batch_pass(d_src, d_dst, E, d_ptr, G, k, reinterpret_cast<int32_t *>(base + o_owner), reinterpret_cast<uint32_t *>(base + o_cnt),
                                                    d_ptr + (G + 1), reinterpret_cast<int64_t *>(base + o_row), reinterpret_cast<int2 *>(base + o_adj),
-                                                   reinterpret_cast<int2 *>(base + o_adjf), ar->d_bump, ar->bump_host, epoch, h_back, s);
+                                                   reinterpret_cast<int2 *>(base + o_adjf), reinterpret_cast<int32_t *>(base + o_vrank), ar->d_bump, ar->bump_host,
+                                                   epoch, h_back, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {       // the counter's value is unknown now: start again from zero
         (void)hipMemset(ar->d_bump, 0, 8); ar->bump_host = 0;
@@ -1181,8 +1224,22 @@ int device_batch_plan(const int64_t *src, const int64_t *dst, int64_t E, const i
     int64_t hits = 0, misses = 0, owned_cols = 0;
     p->g_n.assign((size_t)G, 0); p->g_maxdeg.assign((size_t)G, 0); p->g_sbdeg.assign((size_t)G, 0.0); p->g_level.assign((size_t)G, -1);
     touched.clear();
-    auto give_up = [&] {                                                // put the counters back: the general path repeats the lookups (same final recency order)
-        { std::lock_guard<std::mutex> lk(g_lru_mu); lru().hits -= hits; lru().misses -= misses; }
+    // Graphs the LRU does not know (cold path).  Up to UGS_BATCH_ROOTS_MAX_N vertices the rest of their preprocessing runs on the
+    // device as well (ugs_bp_roots, one launch for all of them behind this loop): the graph exists on the host as a stub.
+    // UGS_DEVICE_COLD=0 keeps the host preprocessing (A/B, tests of both).
+    struct Pending { int64_t g; std::shared_ptr<Graph> gr; uint64_t key; int64_t handle; int64_t roots_off, via_off; };
+    std::vector<Pending> pend;
+    std::vector<int32_t> pend_of((size_t)G, -1);
+    std::vector<std::pair<uint64_t, int64_t>> inserted;                  // (key, handle) this call has put into the LRU
+    const bool cold_on_device = [] { const char *e = std::getenv("UGS_DEVICE_COLD"); return !(e && e[0] == '0'); }();
+    auto give_up = [&] {                                                // put the LRU back as it was: the general path repeats the lookups (same final recency order)
+        {
+            std::lock_guard<std::mutex> lk(g_lru_mu);
+            lru().hits -= hits; lru().misses -= misses;
+            if (evicted.empty()) for (auto &kv : inserted) lru().erase(kv.first);      // (an eviction cannot be undone: then the entries stay, as before)
+        }
+        if (evicted.empty()) for (auto &kv : inserted) drop(kv.second);
+        for (auto &pd : pend) arena_release(dc.id, pd.roots_off, pd.gr->n, pd.via_off, pd.gr->n);
         for (int64_t h : evicted) drop(h);
         return bail(kBatchNotApplicable);
     };
@@ -1202,6 +1259,48 @@ int device_batch_plan(const int64_t *src, const int64_t *dst, int64_t E, const i
         }
         std::shared_ptr<Graph> gr = hit ? lookup(handle) : nullptr;
         if (hit) ++hits; else ++misses;
+        if (!gr && cold_on_device && n <= UGS_BATCH_ROOTS_MAX_N) {       // unknown graph: a stub now, its root records by the launch behind this loop
+            int64_t ro, vo;
+            {
+                std::lock_guard<std::mutex> lk2(g_arena_mu);
+                ro = arena_take(ar->free_roots, ar->roots_used, ar->roots_cap, n);
+                vo = arena_take(ar->free_via, ar->via_used, ar->via_cap, n);
+            }
+            if (ro < 0 || vo < 0) {
+                arena_release(dc.id, ro, ro >= 0 ? n : 0, vo, vo >= 0 ? n : 0);
+                return give_up();                                        // arena full: the general path serves this batch
+            }
+            gr = std::make_shared<Graph>();
+            gr->n = n; gr->nnz = 2 * (int64_t)h_cnt[g]; gr->k_built = k; gr->host_ready = false; gr->stub_lo = lo;
+            if (h_cnt[g]) {                                              // its span of the columns, kept until some host path needs the arrays
+                const int64_t j0 = (int64_t)(0xFFFFFFFFu - h_jminc[g]), j1 = (int64_t)h_jmax[g] + 1;
+                gr->stub_cols.resize((size_t)(2 * (j1 - j0)));
+                std::memcpy(gr->stub_cols.data(), src + j0, (size_t)(j1 - j0) * 8);
+                std::memcpy(gr->stub_cols.data() + (j1 - j0), dst + j0, (size_t)(j1 - j0) * 8);
+            }
+            handle = enroll(gr);
+            {
+                int64_t ev = 0;
+                std::lock_guard<std::mutex> lk(g_lru_mu);
+                if (lru().put(key, handle, ev)) evicted.push_back(ev);
+            }
+            inserted.emplace_back(key, handle);
+            pend_of[(size_t)g] = (int32_t)pend.size();
+            pend.push_back(Pending{g, gr, key, handle, ro, vo});
+            touched.emplace_back(key, handle);
+            graphs[(size_t)g] = gr;
+            continue;
+        }
+        if (gr && !gr->host_ready) {                                     // a stub: of this very call (a repeated graph), or of an earlier one
+            bool mine = false;
+            for (size_t i = 0; i < pend.size() && !mine; ++i) if (pend[i].gr.get() == gr.get()) { pend_of[(size_t)g] = (int32_t)i; mine = true; }
+            if (mine) {
+                if (gr->n != n || gr->nnz != 2 * (int64_t)h_cnt[g]) return give_up();
+                touched.emplace_back(key, handle);
+                graphs[(size_t)g] = gr;
+                continue;
+            }
+        }
         if (!gr) {                                                       // unknown graph: sliced and preprocessed on the host, once
             ru.clear(); rv.clear();
             if (h_cnt[g]) for (int64_t j = (int64_t)(0xFFFFFFFFu - h_jminc[g]); j <= (int64_t)h_jmax[g]; ++j) {
@@ -1214,15 +1313,46 @@ int device_batch_plan(const int64_t *src, const int64_t *dst, int64_t E, const i
             int64_t ev = 0;
             std::lock_guard<std::mutex> lk(g_lru_mu);
             if (lru().put(key, handle, ev)) evicted.push_back(ev);
+            inserted.emplace_back(key, handle);
         }
         if (gr->n != n || gr->nnz != 2 * (int64_t)h_cnt[g]) return give_up();   // a 64-bit key collision: let the general path do what the reference does
         Graph::DevRoots dr{};
         if (int rc = graph_dev_roots(*gr, dc.id, ar, s, dr)) { if (rc == UGS_E_UNSUPPORTED) return give_up(); give_up(); return rc; }
-        d.n = (int32_t)n; d.level = gr->level; d.n_viable = (int32_t)gr->viable.size();
+        d.n = (int32_t)n; d.level = gr->level; d.n_viable = (int32_t)gr->n_viable;
         d.vbase = gr->level == 0 ? dr.roots_off : 0; d.viable_base = gr->level > 0 ? dr.via_off : 0;
         p->g_n[(size_t)g] = n; p->g_maxdeg[(size_t)g] = gr->max_deg; p->g_sbdeg[(size_t)g] = gr->sb_deg; p->g_level[(size_t)g] = gr->level;
         touched.emplace_back(key, handle);
         graphs[(size_t)g] = gr;
+    }
+    if (!pend.empty()) {                                                 // ---- the unknown graphs: root records on the device, 32 bytes each back
+        auto *h_in = reinterpret_cast<UgsBpMissIn *>(static_cast<char *>(ar->pinned) + st_miss);
+        auto *h_out = reinterpret_cast<UgsBpMissOut *>(h_in + G);
+        for (size_t i = 0; i < pend.size(); ++i) h_in[i] = UgsBpMissIn{(int32_t)pend[i].g, 0, pend[i].roots_off, pend[i].via_off};
+        e = ugs_launch_batch_roots(d_ptr, d_ptr + (G + 1), reinterpret_cast<const int64_t *>(base + o_row), reinterpret_cast<const int2 *>(base + o_adj),
+                                   reinterpret_cast<const int32_t *>(base + o_vrank), h_in, h_out, (int64_t)pend.size(), k, ar->roots, ar->via, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { give_up(); return fail_hip(e, "device batch pass: root records"); }
+        for (size_t i = 0; i < pend.size(); ++i) {
+            Graph &gg = *pend[i].gr;
+            const UgsBpMissOut &o = h_out[i];
+            const int64_t n = gg.n;
+            std::lock_guard<std::mutex> lk(gg.pre_mu);
+            if (!gg.host_ready) {                                        // (a host path that met the stub meanwhile has filled in the same values)
+                gg.level = o.level; gg.n_viable = o.n_viable; gg.nonzero = o.nonzero; gg.Z = o.Z; gg.max_deg = o.max_deg; gg.sb_deg = o.sb_deg;
+            }
+            if (o.level == 0) { gg.dev_roots.push_back(Graph::DevRoots{dc.id, pend[i].roots_off, n, -1, 0}); arena_release(dc.id, -1, 0, pend[i].via_off, n); }
+            else { gg.dev_roots.push_back(Graph::DevRoots{dc.id, -1, 0, pend[i].via_off, n}); arena_release(dc.id, pend[i].roots_off, n, -1, 0); }
+        }
+        for (int64_t g = 0; g < G; ++g) {
+            if (pend_of[(size_t)g] < 0) continue;
+            const Pending &pd = pend[(size_t)pend_of[(size_t)g]];
+            const Graph &gg = *pd.gr;
+            UgsGraphDesc &d = desc[(size_t)g];
+            d.n = (int32_t)gg.n; d.level = gg.level; d.n_viable = (int32_t)gg.n_viable;
+            d.vbase = gg.level == 0 ? pd.roots_off : 0; d.viable_base = gg.level > 0 ? pd.via_off : 0;
+            p->g_n[(size_t)g] = gg.n; p->g_maxdeg[(size_t)g] = gg.max_deg; p->g_sbdeg[(size_t)g] = gg.sb_deg; p->g_level[(size_t)g] = gg.level;
+        }
+        pend.clear();
     }
     for (int64_t h : evicted) drop(h);                                   // only evicted handles are destroyed; cached ones live on
     evicted.clear();
@@ -1322,6 +1452,7 @@ int ugs_preproc_dump(int64_t handle, int64_t *indptr, int32_t *indices, int32_t 
                      int32_t *suffix_deg, double *bucket_b, double *prob, int32_t *alias) {
     auto g = lookup(handle);
     if (!g) return fail(UGS_E_INVALID_HANDLE, "Invalid preproc handle");
+    if (!g->host_ready) complete_on_host(*g);
     const size_t n = (size_t)g->n, nnz = (size_t)g->nnz;
     if (indptr) std::memcpy(indptr, g->rowptr.data(), (n + 1) * sizeof(int64_t));
     if (indices && nnz) std::memcpy(indices, g->nbr.data(), nnz * sizeof(int32_t));
@@ -1367,6 +1498,7 @@ int ugs_plan_create_handle(int64_t handle, ugs_plan **plan_out) {
     if (!plan_out) return fail(UGS_E_BAD_ARG, "plan_out is null");
     auto g = lookup(handle);
     if (!g) return fail(UGS_E_INVALID_HANDLE, "Invalid preproc handle");
+    if (!g->host_ready) complete_on_host(*g);
     DeviceCtx dc;
     if (int rc = device_ctx(dc)) return rc;
     std::lock_guard<std::mutex> lk(g->plan_mu);
@@ -1425,11 +1557,16 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
         }
     }
     const int bp_mode = device_batch_mode();
-    if (bp_mode == 1 || (bp_mode == 2 && E >= kBatchPassMinCols)) {   // batches of small graphs: slicing, keys and CSR on the device
+    // A workload the pass cannot take (a graph beyond its limits in every batch, a full arena) would pay upload + pass + wait before
+    // every general-path call: after three refusals in a row the default mode leaves the pass alone for the next 64 calls.
+    static std::atomic<int> bp_refused{0}, bp_pause{0};
+    const bool bp_paused = bp_mode == 2 && bp_pause.load() > 0 && bp_pause.fetch_sub(1) > 0;
+    if (!bp_paused && (bp_mode == 1 || (bp_mode == 2 && E >= kBatchPassMinCols))) {   // batches of small graphs: slicing, keys and CSR on the device
         std::vector<std::pair<uint64_t, int64_t>> touched_d;
         ugs_plan *dp = nullptr;
         const int rc = device_batch_plan(src, dst, E, ptr, G, k, dc, use_index, bh, &dp, touched_d);
         if (rc == UGS_OK) {
+            bp_refused.store(0);
             g_bp_plans.fetch_add(1);
             if (use_index) {
                 std::lock_guard<std::mutex> lk(g_bi_mu);
@@ -1443,6 +1580,7 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
         }
         if (rc != kBatchNotApplicable) return rc;
         g_bp_fallbacks.fetch_add(1);
+        if (bp_refused.fetch_add(1) + 1 >= 3) { bp_refused.store(0); bp_pause.store(64); }
     }
     std::vector<int64_t> cstart, cols_of;                      // per-graph column lists, concatenated
     Lap lap;
@@ -1482,7 +1620,10 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
             std::lock_guard<std::mutex> lk(g_lru_mu);
             if (lru().put(key, handle, ev)) evicted.push_back(ev);
             ++misses;
-        } else ++hits;
+        } else {
+            ++hits;
+            if (!gr->host_ready) complete_on_host(*gr);
+        }
         pc.g = gr;
         touched.emplace_back(key, handle);
         pc.colmap = cols_of.data() + c0;
@@ -1517,6 +1658,38 @@ int ugs_plan_create_batch(const int64_t *edge_index, int64_t row_stride, int64_t
 }
 
 int ugs_plan_release(ugs_plan *plan) { plan_unref(plan); return UGS_OK; }
+
+int ugs_plan_graph_roots(ugs_plan *plan, int64_t graph, int64_t capacity, int32_t *level, int32_t *num_nodes, int32_t *num_viable, double *prob,
+                         int32_t *alias, int32_t *v_self, int32_t *v_alias, int32_t *viable_vi, int32_t *viable_v) {
+    if (!plan || graph < 0 || graph >= plan->G) return fail(UGS_E_BAD_ARG, "graph index outside the plan");
+    HIP_TRY(hipSetDevice(plan->device));
+    UgsGraphDesc d{};
+    {
+        std::lock_guard<std::mutex> lk(plan->mu);
+        if (plan->last_valid) HIP_TRY(hipEventSynchronize(plan->last_ev));
+        HIP_TRY(hipMemcpy(&d, plan->dev.graphs + graph, sizeof(d), hipMemcpyDeviceToHost));
+    }
+    if (level) *level = d.level;
+    if (num_nodes) *num_nodes = d.n;
+    if (num_viable) *num_viable = d.n_viable;
+    if (d.level == 0 && d.n > 0 && (prob || alias || v_self || v_alias)) {
+        if (capacity < d.n) return fail(UGS_E_BAD_ARG, "capacity below the graph's vertex count");
+        std::vector<UgsRootRec> rec((size_t)d.n);
+        HIP_TRY(hipMemcpy(rec.data(), plan->dev.roots + d.vbase, rec.size() * sizeof(UgsRootRec), hipMemcpyDeviceToHost));
+        for (int32_t vi = 0; vi < d.n; ++vi) {
+            if (prob) prob[vi] = rec[(size_t)vi].prob;
+            if (alias) alias[vi] = rec[(size_t)vi].alias;
+            if (v_self) v_self[vi] = rec[(size_t)vi].v_self;
+            if (v_alias) v_alias[vi] = rec[(size_t)vi].v_alias;
+        }
+    } else if (d.level > 0 && d.n_viable > 0 && (viable_vi || viable_v)) {
+        if (capacity < d.n_viable) return fail(UGS_E_BAD_ARG, "capacity below the viable list's length");
+        std::vector<int2> v((size_t)d.n_viable);
+        HIP_TRY(hipMemcpy(v.data(), plan->dev.viable + d.viable_base, v.size() * sizeof(int2), hipMemcpyDeviceToHost));
+        for (int32_t t = 0; t < d.n_viable; ++t) { if (viable_vi) viable_vi[t] = v[(size_t)t].x; if (viable_v) viable_v[t] = v[(size_t)t].y; }
+    }
+    return UGS_OK;
+}
 
 int ugs_plan_info(const ugs_plan *plan, int k, int64_t *num_graphs, int64_t *num_vertices, int64_t *nnz, int64_t *device_bytes, int *tier) {
     if (!plan) return fail(UGS_E_BAD_ARG, "plan is null");
@@ -1798,6 +1971,13 @@ int ugs_plan_twin(ugs_plan *plan, int k, ugs_plan **twin_out) {
     sh->device = plan->device; sh->cus = plan->cus; sh->G = plan->G; sh->nverts = plan->nverts; sh->nnz = plan->nnz;
     {
         std::lock_guard<std::mutex> lk(plan->mu);
+        // The twin shares the owner's device arrays but not its ordering state.  A device-built plan's graph descriptors go up by a
+        // truly asynchronous copy whose only guard is the owner's recorded event (plan_leave): whatever the owner still has in
+        // flight is waited for here, once, so that the twin's first walk on any stream reads finished arrays.
+        if (plan->last_valid) {
+            const hipError_t e = hipEventSynchronize(plan->last_ev);
+            if (e != hipSuccess) { delete sh; return fail(UGS_E_HIP, hipGetErrorString(e)); }
+        }
         sh->dev = plan->dev;
         sh->walk_share = plan->walk_share;
     }

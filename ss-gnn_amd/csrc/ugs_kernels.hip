@@ -173,7 +173,16 @@ __device__ __forceinline__ uint32_t mod64_root(uint64_t x, uint32_t n) {
 // xorshift64* (reference include/sampler.hpp:26-36)
 struct Rng {
     uint64_t s;
-    __device__ __forceinline__ void init(uint64_t seed) { s = seed ? seed : 1ull; }
+    __device__ __forceinline__ void init(uint64_t seed) {
+        s = seed ? seed : 1ull;
+#ifdef UGS_V3
+        // the state is wave-uniform with one walk per wave, and the compiler would keep the generator and everything derived from
+        // it on the scalar unit (49 scalar instructions per draw); opaque to the uniformity analysis it stays on the vector unit
+        uint32_t lo = (uint32_t)s, hi = (uint32_t)(s >> 32);
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        s = ((uint64_t)hi << 32) | lo;
+#endif
+    }
     __device__ __forceinline__ uint64_t next() {
         uint64_t x = s;
         x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
@@ -188,6 +197,7 @@ struct Rng {
 template <int GS> struct Grp {
     int lane;    // 0..GS-1
     int gbase;   // first wave lane of this group
+    uint32_t chain = 0u;   // one walk per wave: lane i holds chain value i (chain_lane_const), set by the walk kernel
     __device__ __forceinline__ void init() {
         int wl = (int)(threadIdx.x & 63);
         lane = wl & (GS - 1);
@@ -822,6 +832,20 @@ __device__ __forceinline__ Pick final_from(const Work<LdsSpace> &ws, const Grp<G
     }
 }
 
+// One walk per wave: lane i < NST keeps B[i] in a register for the whole kernel (the other lanes 0xFFFFFFFF), and the number of chain
+// values below x is the popcount of ONE compare's ballot -- a vector and a scalar instruction where the sign-bit sum below takes
+// 2 NST + (NST - 1) scalar ones.  The scalar unit is the walk kernel's busiest issue port (tools/pad_probe.sh: a scalar instruction
+// costs a wave 12 cycles at the margin, a 4-byte vector one 7), and this runs twice per growth step.
+template <int NST> __device__ __forceinline__ uint32_t chain_lane_const(int lane) {
+    uint32_t v = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) v = lane == i ? kChainHost[i] : v;
+    asm volatile("" : "+v"(v));                                             // keep it: do not rebuild it at every use
+    return v;
+}
+__device__ __forceinline__ int chain_index_below_lanes(uint32_t x, uint32_t chain_lane) {
+    return (int)__popcll(__ballot(chain_lane < x));
+}
 template <int NST> __device__ __forceinline__ int chain_index_below(uint32_t x) {     // number of the first NST chain values < x
     // x <= 2^16: the sign bit of B[i] - x says x > B[i] -- two scalar instructions per term and no condition codes (the
     // compare-and-add form went through a lane mask and a VGPR per term: 6.77 -> 6.61 ms per 1M walks together with the
@@ -841,7 +865,12 @@ __device__ __forceinline__ Pick select_lds(const Work<LdsSpace> &ws, const Grp<G
     // (C5: 96 VGPRs + 52 bytes of scratch -> 88 VGPRs, none; 5.68 -> 5.53 ms per 1M walks).
     Grp<GS> g = g_;
     asm volatile("" : "+v"(g.lane));
+#ifdef UGS_V1
+    int fs;
+    if constexpr (GS == 64) fs = chain_index_below_lanes(c, g_.chain); else fs = chain_index_below<NST>(c);
+#else
     const int fs = chain_index_below<NST>(c);                                 // the final stage: first chain value >= c
+#endif
     materialise_bits<GS, MAXPER, 0, NST>(ws, g, ((1u << fs) - 1u) & ~((1u << nvalid) - 1u));     // stages nvalid .. fs-1
     nvalid = nvalid > fs ? nvalid : fs;
     return final_from<GS, MAXPER, 0, NST>(ws, g, fs, c, rsel);
@@ -880,10 +909,65 @@ __device__ __forceinline__ void stage_hits(StageCtx &sc, const Grp<GS> &g, bool 
     sc.ne += (uint32_t)__popcll(im);
 }
 
+// The probe loops of the membership table for the one-walk-per-wave LDS tiers, written against the EXEC mask directly.  Every
+// active lane probes its own key; a lane is done when it meets an empty slot (and, inserting, has taken it) or its key.  The
+// compiler's version of this loop -- unrolled eight times, one saved EXEC mask per level and two scalar instructions per level on
+// the way out -- spends ~6 scalar instructions per probe; here the two `v_cmpx` narrow EXEC to the lanes still probing, the loop
+// ends when EXEC is empty and the entry mask is restored once.  No scalar ALU instruction inside the loop.
+// The table is never full (scan_chunk's hlimit guard), and the probe step is odd, so every lane terminates.
+__device__ __forceinline__ uint32_t probe_insert_lds(uint32_t *HK, uint32_t hmask, uint32_t slot, uint32_t step, uint32_t w, uint32_t &seen) {
+    const uint32_t base = (uint32_t)(uintptr_t)HK;                            // low half of a flat LDS pointer = its LDS address
+    uint32_t addr = base + (slot << 2), t;
+    uint64_t saved;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n"
+        "ugs_pi_%=:\n"
+        "ds_cmpst_rtn_b32 %[seen], %[addr], %[empty], %[neww]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_and_b32 %[t], 0x3fffffff, %[seen]\n"
+        "v_cmpx_ne_u32 -1, %[seen]\n"
+        "v_cmpx_ne_u32 %[t], %[w]\n"
+        "s_cbranch_execz ugs_pd_%=\n"
+        "v_add_u32 %[slot], %[slot], %[step]\n"
+        "v_and_b32 %[slot], %[hmask], %[slot]\n"
+        "v_lshl_add_u32 %[addr], %[slot], 2, %[base]\n"
+        "s_branch ugs_pi_%=\n"
+        "ugs_pd_%=:\n"
+        "s_mov_b64 exec, %[sv]\n"
+        : [seen] "+v"(seen), [slot] "+v"(slot), [addr] "+v"(addr), [t] "=&v"(t), [sv] "=&s"(saved)
+        : [empty] "v"(kEmpty), [neww] "v"(w | kFresh), [w] "v"(w), [step] "v"(step), [hmask] "s"(hmask), [base] "s"(base)
+        : "vcc", "memory");
+    return slot;
+}
+__device__ __forceinline__ void probe_find_lds(const uint32_t *HK, uint32_t hmask, uint32_t slot, uint32_t step, uint32_t w, uint32_t &seen) {
+    const uint32_t base = (uint32_t)(uintptr_t)HK;
+    uint32_t addr = base + (slot << 2), t;
+    uint64_t saved;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n"
+        "ugs_pf_%=:\n"
+        "ds_read_b32 %[seen], %[addr]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_and_b32 %[t], 0x3fffffff, %[seen]\n"
+        "v_cmpx_ne_u32 -1, %[seen]\n"
+        "v_cmpx_ne_u32 %[t], %[w]\n"
+        "s_cbranch_execz ugs_pe_%=\n"
+        "v_add_u32 %[slot], %[slot], %[step]\n"
+        "v_and_b32 %[slot], %[hmask], %[slot]\n"
+        "v_lshl_add_u32 %[addr], %[slot], 2, %[base]\n"
+        "s_branch ugs_pf_%=\n"
+        "ugs_pe_%=:\n"
+        "s_mov_b64 exec, %[sv]\n"
+        : [seen] "+v"(seen), [slot] "+v"(slot), [addr] "+v"(addr), [t] "=&v"(t), [sv] "=&s"(saved)
+        : [w] "v"(w), [step] "v"(step), [hmask] "s"(hmask), [base] "s"(base)
+        : "vcc", "memory");
+}
+
 // One chunk of an adjacency row: lane holds entry e (neighbour, rank) at CSR position p (a plan has < 2^31 entries); lanes
 // without an entry hold kNoEntry, whose rank -1 fails the suffix filter, so `cand` is one signed compare (ranks are < 2^30).
 #define UGS_NO_ENTRY make_int2(0, -1)
-template <int GS, class SP, bool ADD, bool STG>
+// GUARD = false: the caller has checked that the whole row fits (candidates and table entries), so the per-chunk tests are left out.
+template <int GS, class SP, bool ADD, bool STG, bool GUARD = true>
 __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g, uint32_t v, uint32_t root_vi, uint32_t size, uint32_t &c,
                                            uint32_t &hcount, uint32_t &ecount, StageCtx &sc, int2 e, uint32_t p) {
     const uint32_t w = (uint32_t)e.x;
@@ -892,10 +976,15 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
     const uint32_t step = hash_step(w);
     bool in_s = false;
     if (ADD) {
-        if (hcount + (uint32_t)__popcll(g.ballot(cand)) > ws.hlimit) return false;
+        if constexpr (GUARD) { if (hcount + (uint32_t)__popcll(g.ballot(cand)) > ws.hlimit) return false; }
         // probe: only `seen` and `slot` are carried round the loop; what happened is read off `seen` afterwards
         uint32_t seen = kKeyMask;                                 // a value no probe returns for a candidate
         STAMP_SUB_BEGIN();
+#ifdef UGS_V4
+        if constexpr (GS == 64 && sizeof(typename SP::TW) == 4) {
+            if (cand) slot = probe_insert_lds(ws.HK, ws.hmask, slot, step, w, seen);
+        } else
+#endif
         if (cand) {
             for (uint32_t it = 0; it <= ws.hmask; ++it) {         // the table is never full
                 seen = atomicCAS(&ws.HK[slot], kEmpty, w | kFresh);
@@ -925,6 +1014,10 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
             dupm &= ~grp;
         }
         if (inserted) ws.HK[slot] = w;                            // the chunk is over for this key: drop kFresh
+#ifdef UGS_V5
+        if constexpr (GS == 64) ecount += in_s ? (w == v ? 1u : 2u) : 0u;       // per lane, summed over the wave at the end of the walk
+        else
+#endif
         {   // entries to earlier members count twice (the mirror entry), entries to the scanned vertex itself once
             const uint64_t im = g.ballot(in_s), sm = g.ballot(w == v);
             ecount += 2u * (uint32_t)__popcll(im & ~sm) + (uint32_t)__popcll(im & sm);
@@ -932,13 +1025,18 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
         if constexpr (STG) { if (sc.on) stage_hits<GS>(sc, g, in_s, w, p, size); }
         const uint64_t fm = g.ballot(first);
         const uint32_t nnew = (uint32_t)__popcll(fm);
-        if (c + nnew > ws.cap) return false;
+        if constexpr (GUARD) { if (c + nnew > ws.cap) return false; }
         if (first) ws.D[c + g.below(fm)] = w;
         c += nnew;
         hcount += nnew;
         SP::sync();
     } else {
         uint32_t seen = kEmpty;
+#ifdef UGS_V4
+        if constexpr (GS == 64 && sizeof(typename SP::TW) == 4) {
+            if (cand) probe_find_lds(ws.HK, ws.hmask, slot, step, w, seen);
+        } else
+#endif
         if (cand) {
             for (uint32_t it = 0; it <= ws.hmask; ++it) {
                 seen = ws.HK[slot];
@@ -947,6 +1045,10 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
             }
         }
         in_s = (seen & (kKeyMask | kInS)) == (w | kInS);                     // kEmpty (no candidate, or not seen) matches no vertex
+#ifdef UGS_V5
+        if constexpr (GS == 64) ecount += in_s ? (w == v ? 1u : 2u) : 0u;
+        else
+#endif
         {
             const uint64_t im = g.ballot(in_s), sm = g.ballot(w == v);
             ecount += 2u * (uint32_t)__popcll(im & ~sm) + (uint32_t)__popcll(im & sm);
@@ -972,9 +1074,19 @@ __device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, c
 
 // padded row of v (one walk per wave): `e0` = entry `lane` of the row's block, loaded by the caller as soon as v was known.
 // Lane 0 holds the header (degree, CSR position of the first entry), lanes 1.. the first entries; a longer row continues in adj[].
+__device__ __forceinline__ int2 prow_entry(const UgsPlanDev &P, int64_t vrow, int lane) {
+#ifdef UGS_V8
+    // the padded rows of a plan span less than 4 GB (ensure_prow), so an entry's byte offset fits 32 bits: one shift-add per lane
+    // and the scalar base in the load, instead of 64-bit vector address arithmetic
+    const uint32_t off = (((uint32_t)vrow << P.prow_shift) + (uint32_t)lane) << 3;
+    return *reinterpret_cast<const int2 *>(reinterpret_cast<const char *>(P.prow) + off);
+#else
+    return P.prow[(vrow << P.prow_shift) + lane];
+#endif
+}
 __device__ __forceinline__ int2 load_prow(const UgsPlanDev &P, int64_t vrow, int lane) {
     int2 e = make_int2(0, 0);
-    if (lane < P.prow_first) e = P.prow[(vrow << P.prow_shift) + lane];
+    if (lane < P.prow_first) e = prow_entry(P, vrow, lane);
     return e;
 }
 
@@ -987,9 +1099,24 @@ __device__ __forceinline__ bool scan_prow(const Work<SP> &ws, const Grp<64> &g, 
     const uint32_t inl = (1u << P.prow_shift) - 1u;                              // entries held by the block itself
     const uint32_t n0 = deg < inl ? deg : inl;
     if (n0 >= (uint32_t)P.prow_first) {                                          // the row reaches into the lines not fetched yet
-        if (g.lane >= P.prow_first && g.lane <= (int)n0) e0 = P.prow[(vrow << P.prow_shift) + g.lane];
+        if (g.lane >= P.prow_first && g.lane <= (int)n0) e0 = prow_entry(P, vrow, g.lane);
     }
     if ((uint32_t)(g.lane - 1) >= n0) e0 = UGS_NO_ENTRY;                        // the header's lane and the lanes behind the row
+#ifdef UGS_V6
+    // a row whose every entry could be a new candidate and still fit needs no per-chunk overflow tests (nearly all rows); the
+    // others take the guarded chunks, so the walks a tier hands on are exactly those it handed on before
+    if (ADD && hcount + deg <= ws.hlimit && c + deg <= ws.cap) {
+        if (n0) scan_chunk<64, SP, ADD, STG, false>(ws, g, v, root_vi, size, c, hcount, ecount, sc, e0, start + (uint32_t)g.lane - 1u);
+        const uint32_t r1 = start + deg;
+        for (uint32_t base = start + inl; base < r1; base += 64) {
+            const uint32_t p = base + (uint32_t)g.lane;
+            int2 e = UGS_NO_ENTRY;
+            if (p < r1) e = P.adj[p];
+            scan_chunk<64, SP, ADD, STG, false>(ws, g, v, root_vi, size, c, hcount, ecount, sc, e, p);
+        }
+        return true;
+    }
+#endif
     if (n0 && !scan_chunk<64, SP, ADD, STG>(ws, g, v, root_vi, size, c, hcount, ecount, sc, e0, start + (uint32_t)g.lane - 1u)) return false;
     const uint32_t r1 = start + deg;
     for (uint32_t base = start + inl; base < r1; base += 64) {
@@ -1178,6 +1305,9 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
         {   // stages whose candidates all precede position q keep their order
             int keep = 0;
             if constexpr (sizeof(typename SP::TW) == 4) {                     // LDS tiers: the chain values are immediates
+#ifdef UGS_V1
+                if constexpr (GS == 64) keep = chain_index_below_lanes(q + 1u, g_.chain); else
+#endif
                 keep = chain_index_below<nst_of(MAXPER * GS)>(q + 1u);        // number of B[i] <= q
                 keep = keep < nvalid ? keep : nvalid;
             } else {
@@ -1190,11 +1320,26 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
         {   // w is now a member of the sample: flag its hash entry (the group probes GS consecutive slots per round trip)
             const uint32_t step = hash_step(w);
             uint32_t s = (hash_slot(w, ws.hmask) + (uint32_t)g.lane * step) & ws.hmask;
+#ifdef UGS_V2
+            // lane i looks at the i-th slot of w's probe sequence; the entry is there (w was a candidate) and almost always among
+            // the first GS slots, so the loop is written around that case: read, compare, one scalar test, write
+            bool hit = ws.HK[s] == w;                                 // a candidate's entry carries no flag
+            for (uint32_t it = GS; __builtin_expect(!g.any(hit), 0) && it <= ws.hmask; it += GS) {
+                s = (s + GS * step) & ws.hmask;
+                hit = ws.HK[s] == w;
+            }
+            if (hit) ws.HK[s] = w | kInS;
+#else
             for (uint32_t it = 0; it <= ws.hmask; it += GS) {         // lane i looks at the i-th slot of w's probe sequence
                 const bool hit = ws.HK[s] == w;                       // a candidate's entry carries no flag
                 if (g.any(hit)) { if (hit) ws.HK[s] = w | kInS; break; }
                 s = (s + GS * step) & ws.hmask;
             }
+#endif
+#ifdef UGS_V7
+            if constexpr (GS == 64) SV[size] = w;                     // every lane, same word, same value: no lane-0 mask to set up
+            else
+#endif
             if (g.lane == 0) SV[size] = w;
         }
         size += 1;
@@ -1202,6 +1347,9 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
         SP::sync();
         STAMP_END(3);
     }
+#ifdef UGS_V5
+    if constexpr (GS == 64) ecount = g.last(g.prefix_incl(ecount));              // the lanes' counts -> the row's
+#endif
     const uint32_t nedges = (size == (uint32_t)k) ? ecount : 0u;                // incomplete rows carry no edges (:219-223)
     // staged hits: fetch their edge columns now, the row's epilogue below runs while the gather is in flight
     bool flush = false;
@@ -1250,6 +1398,9 @@ __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP == 704 ?
     __shared__ __attribute__((aligned(16))) uint32_t lds[GROUPS * Cfg::WORDS];
     Grp<GS> g;
     g.init();
+#ifdef UGS_V1
+    if constexpr (GS == 64) g.chain = chain_lane_const<Cfg::NSTAGE>(g.lane);
+#endif
     const int gib = (int)threadIdx.x / GS;
     uint32_t *base = lds + gib * Cfg::WORDS;
     Work<LdsSpace> ws;

@@ -315,6 +315,17 @@ class Plan:
         check(lib.ugs_plan_twin(self._h, self.k, C.byref(h)))
         return Plan(h, self.num_graphs, self.k)
 
+    def graph_roots(self, graph, capacity):
+        """What the walk kernels read for one graph of the plan, copied back from HBM (testing aid): level, and per order position
+        prob / alias / v_self / v_alias (level 0) or the viable list (levels 1, 2)."""
+        import numpy as np
+        lvl, n, nvia = C.c_int32(), C.c_int32(), C.c_int32()
+        d = {"prob": np.zeros(capacity, np.float64), "alias": np.zeros(capacity, np.int32), "v_self": np.zeros(capacity, np.int32),
+             "v_alias": np.zeros(capacity, np.int32), "viable_vi": np.zeros(capacity, np.int32), "viable_v": np.zeros(capacity, np.int32)}
+        check(lib.ugs_plan_graph_roots(self._h, int(graph), int(capacity), C.byref(lvl), C.byref(n), C.byref(nvia), *[v.ctypes.data for v in d.values()]))
+        d.update(level=lvl.value, num_nodes=n.value, num_viable=nvia.value)
+        return d
+
     def info(self):
         g, nv, nnz, nb, tier = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
         check(lib.ugs_plan_info(self._h, self.k, C.byref(g), C.byref(nv), C.byref(nnz), C.byref(nb), C.byref(tier)))

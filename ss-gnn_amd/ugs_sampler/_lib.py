@@ -45,6 +45,7 @@ def _load():
         "ugs_plan_create_batch": [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int, C.POINTER(vp)],
         "ugs_plan_create_handle": [C.c_int64, C.POINTER(vp)],
         "ugs_plan_release": [vp],
+        "ugs_plan_graph_roots": [vp, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)] + [vp] * 6,
         "ugs_plan_twin": [vp, C.c_int, C.POINTER(vp)],
         "ugs_plan_info": [vp, C.c_int, i64p, i64p, i64p, i64p, C.POINTER(C.c_int)],
         "ugs_plan_walk": [vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int64, vp, vp, vp, i64p],

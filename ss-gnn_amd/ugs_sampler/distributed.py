@@ -39,16 +39,22 @@ def shard_offsets(total_rows, world, weights=None):
         w = [float(x) for x in weights]
         if len(w) != world or any(not (x >= 0.0) or x == float("inf") for x in w) or not sum(w) > 0.0:
             raise ValueError("shard weights: one finite non-negative number per rank, not all zero")
-        tot_w = sum(w)
-        exact = [total * x / tot_w for x in w]
-        sizes = [int(e) for e in exact]
+        # exact rational arithmetic: every float is a ratio of integers, so the quotas total * w[r] / sum(w) are compared and
+        # floored without rounding -- the sizes always add up to `total` (floating-point floors could overshoot it)
+        from fractions import Fraction
+        fw = [Fraction(x) for x in w]
+        tot_w = sum(fw)
+        exact = [total * x / tot_w for x in fw]
+        sizes = [e.numerator // e.denominator for e in exact]
         left = total - sum(sizes)
+        assert 0 <= left < world or (left == 0 and world == 0)
         order = sorted(range(world), key=lambda r: (-(exact[r] - sizes[r]), r))
         for r in order[:left]:
             sizes[r] += 1
     off = [0]
     for c in sizes:
         off.append(off[-1] + c)
+    assert off[-1] == total
     return off
 
 
