@@ -240,11 +240,10 @@ class Job:
         self.totals = None
 
     def sample(self, i):
-        """walk + scan + fill of step i (asynchronous) on the stream of buffer set i % nsets"""
+        """walk + scan + fill of step i (asynchronous; Plan.step) on the stream of buffer set i % nsets"""
         b = i % self.nsets
         with self.torch.cuda.stream(self.streams[b]):
-            self.plans[b].walk(self.m_total, self.args.mode, 42 + i, self.row_begin, self.row_count, out=(self.nodes[b], self.eptr[b]), sync=False)
-            self.plans[b].fill(self.m_total, self.nodes[b], self.eptr[b], None, self.args.mode, self.row_begin, out=(self.eidx[b], self.esrc[b]))
+            self.plans[b].step(self.m_total, self.args.mode, 42 + i, self.row_begin, self.row_count, out=(self.nodes[b], self.eptr[b], self.eidx[b], self.esrc[b]))
             if self.totals is not None:
                 self.totals[i] = self.eptr[b][-1]
 
@@ -670,16 +669,14 @@ def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
     eidx = torch.empty((2, cap), dtype=torch.int64, device=dev)
     esrc = torch.empty((cap,), dtype=torch.int64, device=dev)
     for i in range(5):
-        plan.walk(m, "sample", 42 + i, 0, rows, out=(nodes, eptr), sync=False)
-        plan.fill(m, nodes, eptr, None, "sample", 0, out=(eidx, esrc))
+        plan.step(m, "sample", 42 + i, 0, rows, out=(nodes, eptr, eidx, esrc))
     torch.cuda.synchronize()
     evs = []
     t = time.perf_counter()
     for i in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        plan.walk(m, "sample", 42 + i, 0, rows, out=(nodes, eptr), sync=False)
-        plan.fill(m, nodes, eptr, None, "sample", 0, out=(eidx, esrc))
+        plan.step(m, "sample", 42 + i, 0, rows, out=(nodes, eptr, eidx, esrc))
         b.record()
         evs.append((a, b))
     torch.cuda.synchronize()
@@ -688,8 +685,7 @@ def bench_small(name, ugs_sampler, wl, torch, dev, reps=50):
     # so that the events do not sit inside the step times above), SURVEY.md 8(d) bytes measured on the step's own output
     plan.set_timing(True)
     for i in range(reps):
-        plan.walk(m, "sample", 42 + i, 0, rows, out=(nodes, eptr), sync=False)
-        plan.fill(m, nodes, eptr, None, "sample", 0, out=(eidx, esrc))
+        plan.step(m, "sample", 42 + i, 0, rows, out=(nodes, eptr, eidx, esrc))
     torch.cuda.synchronize()
     tk = plan.get_timing()
     plan.set_timing(False)

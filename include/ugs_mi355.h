@@ -148,6 +148,14 @@ int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
 int ugs_plan_fill(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int64_t row_begin,
                   int64_t row_count, void *stream, const int64_t *d_nodes, const int64_t *d_edge_ptr,
                   int64_t *d_edge_index, int64_t ld, int64_t *d_edge_src);
+/* Walk + fill of the same rows as ONE call, for callers that hand over edge buffers of capacity ld up front (no host read-back
+ * of the total in between: d_edge_ptr[row_count] holds it afterwards).  Same outputs as ugs_plan_walk followed by ugs_plan_fill
+ * (reference src/sampler.cpp:91-290).  Knowing that nobody reads edge_ptr between the two phases, the step of a batch of small
+ * graphs runs in two launches instead of three: the fill kernel scans the per-row counts itself (decoupled look-back over tiles
+ * of 32 rows; `UGS_NO_FUSED_SCAN` set = the three-launch form). */
+int ugs_plan_step(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int seed, int64_t row_begin,
+                  int64_t row_count, void *stream, int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *d_edge_index, int64_t ld,
+                  int64_t *d_edge_src);
 /* Share (1..100 percent, default 100) of the blocks a CU can hold that this plan's walk kernels occupy.  The walk kernels are
  * persistent grids that keep every CU's registers, LDS and wave slots to their end; a job that runs other kernels BESIDE a walk
  * (the collation of the previous batch and its RCCL transfer on another stream) lowers the share so that those find room on

@@ -508,6 +508,11 @@ struct ugs_plan {
     // edges staged by the last walk (UgsWalkArgs::stage) and the call they belong to: a fill of exactly those rows into/from
     // the same nodes buffer expands them; any other fill reads the adjacency rows again
     PoolBuf stage, ulist, work;   // work: 3 x u64 next-item counters (one per walk launch of a call)
+    // scan folded into the fill (ugs_plan_step, ugs_fill_scan): [ticket counter | pad to 64 B | one state word per tile of 32 rows].
+    // The counter is never reset (the host mirrors it), states carry the launch's epoch: no memset between steps.
+    PoolBuf tiles;
+    unsigned long long tile_tickets = 0;
+    uint32_t tile_epoch = 0;
     // stream order between calls: a plan's scratch is reused by every call, so a call on another stream than the previous one
     // first waits (on the device) for that call's last kernel
     hipEvent_t last_ev = nullptr;
@@ -713,7 +718,7 @@ void destroy_plan(ugs_plan *p) {
     if (p->last_ev) (void)hipEventDestroy(p->last_ev);
     if (p->blob_buf.p) pool_put(p->blob_buf); else if (p->blob) (void)hipFree(p->blob);
     pool_put(p->counts); pool_put(p->ovf1); pool_put(p->ovf2); pool_put(p->ovfcnt); pool_put(p->scantmp);
-    pool_put(p->stage); pool_put(p->ulist); pool_put(p->work);
+    pool_put(p->stage); pool_put(p->ulist); pool_put(p->work); pool_put(p->tiles);
     if (p->prow.p) { if (p->prow_pooled) pool_put(p->prow); else (void)hipFree(p->prow.p); p->prow = PoolBuf(); }
     if (p->gws.p) { (void)hipFree(p->gws.p); p->gws = PoolBuf(); }
     ugs_plan *owner = p->twin_of;
@@ -1702,15 +1707,20 @@ int ugs_plan_info(const ugs_plan *plan, int k, int64_t *num_graphs, int64_t *num
 }
 
 static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int seed, const uint64_t *d_seed_ptr,
-                          int64_t row_begin, int64_t row_count, void *stream, int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *total_edges_host);
+                          int64_t row_begin, int64_t row_count, void *stream, int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *total_edges_host,
+                          bool *defer_scan = nullptr);
 
 int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int seed, int64_t row_begin,
                   int64_t row_count, void *stream, int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *total_edges_host) {
     return plan_walk_impl(plan, m_per_graph, k, mode, extra_node_offset, seed, nullptr, row_begin, row_count, stream, d_nodes, d_edge_ptr, total_edges_host);
 }
 
+// defer_scan (ugs_plan_step): where the fill kernel can turn the counts into edge_ptr itself -- first tier S (rows are filled from
+// their adjacency, nothing is staged), no capture in progress -- the scan launch is left out and *defer_scan set.
 static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int seed, const uint64_t *d_seed_ptr,
-                          int64_t row_begin, int64_t row_count, void *stream, int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *total_edges_host) {
+                          int64_t row_begin, int64_t row_count, void *stream, int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *total_edges_host,
+                          bool *defer_scan) {
+    if (defer_scan) *defer_scan = false;
     if (!plan) return fail(UGS_E_BAD_ARG, "plan is null");
     if (k < 1) return fail(UGS_E_BAD_ARG, "k must be >= 1");
     if (k > UGS_KMAX) return fail(UGS_E_UNSUPPORTED, "k > 32 is not supported by the HIP sampler");
@@ -1812,7 +1822,9 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
         HIP_TRY(ugs_launch_walk(a, UGS_TIER_G, plan->cus, plan->walk_share, s, nullptr));
         last = 2;
     }
-    HIP_TRY(ugs_launch_scan(static_cast<const uint32_t *>(plan->counts.p), row_count, d_edge_ptr, static_cast<int64_t *>(plan->scantmp.p), s));
+    const bool defer = defer_scan && !total_edges_host && tc.first == UGS_TIER_S && !capturing(s) && std::getenv("UGS_NO_FUSED_SCAN") == nullptr;
+    if (defer) *defer_scan = true;
+    else HIP_TRY(ugs_launch_scan(static_cast<const uint32_t *>(plan->counts.p), row_count, d_edge_ptr, static_cast<int64_t *>(plan->scantmp.p), s));
     HIP_TRY(ev_end(plan, s));
     if (int rc = plan_leave(plan, s)) return rc;
     if (total_edges_host) {
@@ -1857,6 +1869,44 @@ int ugs_plan_fill(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
     HIP_TRY(ugs_launch_fill(a, tc.first != UGS_TIER_S, plan->cus, static_cast<hipStream_t>(stream), &plan->last_fill));
     HIP_TRY(ev_end(plan, static_cast<hipStream_t>(stream)));
     return plan_leave(plan, static_cast<hipStream_t>(stream));
+}
+
+int ugs_plan_step(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int seed, int64_t row_begin, int64_t row_count,
+                  void *stream, int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *d_edge_index, int64_t ld, int64_t *d_edge_src) {
+    bool deferred = false;
+    if (int rc = plan_walk_impl(plan, m_per_graph, k, mode, extra_node_offset, seed, nullptr, row_begin, row_count, stream, d_nodes, d_edge_ptr,
+                                nullptr, &deferred)) return rc;
+    if (!deferred || row_count <= 0)
+        return ugs_plan_fill(plan, m_per_graph, k, mode, extra_node_offset, row_begin, row_count, stream, d_nodes, d_edge_ptr, d_edge_index, ld, d_edge_src);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(plan->device));
+    std::lock_guard<std::mutex> lk(plan->mu);
+    if (int rc = plan_enter(plan, s)) return rc;
+    const int64_t tiles = ugs_fill_scan_tiles(row_count);
+    const size_t need = 64 + (size_t)tiles * sizeof(unsigned long long);
+    const bool fresh = !plan->tiles.p || plan->tiles.bytes < need;
+    if (fresh) { if (int rc = ensure(plan->tiles, std::max<size_t>(need, 4096), plan->device, plan)) return rc; }
+    if (fresh || ++plan->tile_epoch >= (1u << 24)) {        // a buffer from the pool holds anything; a wrapped epoch would meet its own old states
+        HIP_TRY(hipMemsetAsync(plan->tiles.p, 0, plan->tiles.bytes, s));
+        plan->tile_tickets = 0; plan->tile_epoch = 1;
+    }
+    UgsFillArgs a{};
+    a.plan = plan->dev;
+    a.m = m_per_graph; a.k = k; a.mode = mode;
+    a.extra_node_off = extra_node_offset;
+    a.row_begin = row_begin; a.row_count = row_count;
+    a.nodes = d_nodes; a.edge_ptr = d_edge_ptr; a.edge_ptr_out = d_edge_ptr;
+    a.edge_index = d_edge_index; a.ld = ld; a.edge_src = d_edge_src;
+    a.counts = static_cast<const uint32_t *>(plan->counts.p);
+    a.ticket = static_cast<unsigned long long *>(plan->tiles.p);
+    a.tile_state = a.ticket + 8;
+    a.ticket_base = plan->tile_tickets; a.epoch = plan->tile_epoch;
+    int64_t used = 0;
+    HIP_TRY(ev_begin(plan, 2, s));
+    HIP_TRY(ugs_launch_fill_scan(a, plan->cus, s, &plan->last_fill, &used));
+    plan->tile_tickets += (unsigned long long)used;
+    HIP_TRY(ev_end(plan, s));
+    return plan_leave(plan, s);
 }
 
 // ---- a step captured as a HIP graph (include/ugs_mi355.h) -----------------------------------------------------------------

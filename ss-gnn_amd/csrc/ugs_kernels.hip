@@ -1765,6 +1765,108 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
     }
 }
 
+// The small-batch step in two launches instead of three: the fill kernel of the 8-lane tier with the exclusive scan of the walk's
+// per-row counts folded in (reference semantics of edge_ptr: src/sampler.cpp:249-287).  A block takes tiles of 32 consecutive rows in
+// TICKET order (so every tile in front of a running tile has been started), publishes its tile's sum, and finds the sum of all
+// tiles in front of it by decoupled look-back: one wave reads the states of the 64 preceding tiles at a time, adds the sums up
+// to the nearest tile that already knows its own prefix, and publishes its prefix in turn.  A tile publishes its sum before it
+// waits for anything, and tile 0 knows its prefix at once, so the chain cannot stall; tiles are uniform and short (32 counts), so
+// a look-back rarely waits at all.  One 64-bit word per tile carries launch epoch, flag and value together: no ordering between
+// separate words is needed, and no memset between launches (stale epochs read as "not yet").
+constexpr int kFsEpochShift = 40, kFsFlagShift = 38;
+constexpr unsigned long long kFsValueMask = (1ull << kFsFlagShift) - 1ull;
+__device__ __forceinline__ unsigned long long fs_pack(uint32_t epoch, uint32_t flag, unsigned long long v) {
+    return ((unsigned long long)epoch << kFsEpochShift) | ((unsigned long long)flag << kFsFlagShift) | (v & kFsValueMask);
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += (unsigned long long)__shfl_xor((long long)x, d, 64);
+    return x;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void ugs_fill_scan(UgsFillArgs a) {
+    constexpr int GS = 8, GROUPS = BLOCK / GS;
+    static_assert(GROUPS <= 64, "one wave scans a tile's counts");
+    __shared__ uint32_t sv_all[GROUPS * UGS_KMAX];
+    __shared__ uint32_t ps_all[GROUPS * (UGS_KMAX + 1)];
+    __shared__ int64_t r0_all[GROUPS * UGS_KMAX];
+    __shared__ uint32_t cnt_sh[GROUPS];
+    __shared__ unsigned long long excl_sh[GROUPS];
+    __shared__ unsigned long long front_sh;
+    __shared__ unsigned long long tile_sh;
+    Grp<GS> g;
+    g.init();
+    const int gib = (int)threadIdx.x / GS;
+    uint32_t *SV = sv_all + gib * UGS_KMAX;
+    uint32_t *PS = ps_all + gib * (UGS_KMAX + 1);
+    int64_t *R0 = r0_all + gib * UGS_KMAX;
+    const UgsPlanDev &P = a.plan;
+    const int k = a.k;
+    const unsigned long long ntiles = (unsigned long long)((a.row_count + GROUPS - 1) / GROUPS);
+    for (;;) {
+        if (threadIdx.x == 0) tile_sh = atomicAdd(a.ticket, 1ull) - a.ticket_base;
+        __syncthreads();
+        const unsigned long long tile = tile_sh;
+        if (tile >= ntiles) break;
+        const int64_t row_rel = (int64_t)tile * GROUPS + gib;
+        const bool in = row_rel < a.row_count;
+        const uint32_t c = in ? (a.counts[row_rel] & ~UGS_COUNT_STAGED) : 0u;
+        if (g.lane == 0) cnt_sh[gib] = c;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int lane = (int)threadIdx.x;
+            const uint32_t x = lane < GROUPS ? cnt_sh[lane] : 0u;
+            uint32_t incl = x;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+            const unsigned long long S = (unsigned long long)__shfl(incl, 63, 64);
+            if (lane < GROUPS) excl_sh[lane] = (unsigned long long)(incl - x);
+            unsigned long long front = 0ull;
+            if (tile == 0ull) {
+                if (lane == 0) __hip_atomic_store(&a.tile_state[0], fs_pack(a.epoch, 2u, S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (lane == 0) __hip_atomic_store(&a.tile_state[tile], fs_pack(a.epoch, 1u, S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                long long base = (long long)tile - 1;
+                for (;;) {
+                    const long long idx = base - lane;
+                    unsigned long long st = fs_pack(a.epoch, 2u, 0ull);                    // in front of tile 0: prefix 0
+                    if (idx >= 0) st = __hip_atomic_load(&a.tile_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t fl = (uint32_t)(st >> kFsFlagShift) & 3u;
+                    const bool ok = (uint32_t)(st >> kFsEpochShift) == a.epoch && fl != 0u;
+                    const uint64_t pm = __ballot(ok && fl == 2u), bad = __ballot(!ok);
+                    const unsigned long long v = st & kFsValueMask;
+                    if (pm) {
+                        const int L = __ffsll((long long)pm) - 1;                          // nearest tile that knows its prefix
+                        if (bad & ((1ull << L) - 1ull)) { __builtin_amdgcn_s_sleep(1); continue; }   // a nearer tile has not published yet
+                        front += wave_sum_u64(lane <= L ? v : 0ull);
+                        break;
+                    }
+                    if (bad) { __builtin_amdgcn_s_sleep(1); continue; }
+                    front += wave_sum_u64(v);
+                    base -= 64;
+                }
+                if (lane == 0) __hip_atomic_store(&a.tile_state[tile], fs_pack(a.epoch, 2u, front + S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0) front_sh = front;
+        }
+        __syncthreads();
+        const int64_t e0 = (int64_t)(front_sh + excl_sh[gib]);
+        if (in && g.lane == 0) {
+            a.edge_ptr_out[row_rel] = e0;
+            if (row_rel == a.row_count - 1) a.edge_ptr_out[a.row_count] = e0 + (int64_t)c;
+        }
+        if (in && c != 0u) {
+            const int64_t row = a.row_begin + row_rel;
+            int64_t gi, i;
+            if (P.num_graphs == 1) { gi = 0; i = row; }
+            else { gi = row / a.m; i = row - gi * a.m; }
+            const UgsGraphDesc gd = P.graphs[gi];
+            fill_row<GS>(a, P, g, gd, row_rel, i, e0, a.nodes + row_rel * k, nullptr, SV, PS, R0);
+        }
+        __syncthreads();
+    }
+}
 
 }  // namespace
 
@@ -1902,6 +2004,21 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill_staged(UgsFillArgs a) {
             a.edge_src[e0 + t] = (int64_t)(int32_t)x.x;
         }
     }
+}
+
+int64_t ugs_fill_scan_tiles(int64_t rows) { return (rows + 31) / 32; }
+
+hipError_t ugs_launch_fill_scan(const UgsFillArgs &a, int cus, hipStream_t s, UgsLaunchInfo *info, int64_t *tickets_used) {
+    if (cus <= 0) cus = 256;
+    constexpr int BLOCK = 256, GROUPS = 32;
+    const int64_t tiles = (a.row_count + GROUPS - 1) / GROUPS;
+    int64_t grid = tiles;
+    if (grid > (int64_t)cus * 8) grid = (int64_t)cus * 8;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((ugs_fill_scan<BLOCK>), dim3((unsigned)grid), dim3(BLOCK), 0, s, a);
+    if (info) { info->name = "ugs_fill_scan<8>"; info->grid = (int)grid; info->block = BLOCK; info->lds_bytes = GROUPS * UGS_KMAX * 4; }
+    if (tickets_used) *tickets_used = tiles + grid;             // every block ends on the first ticket beyond the tiles
+    return hipGetLastError();
 }
 
 hipError_t ugs_launch_fill(const UgsFillArgs &a, int wide, int cus, hipStream_t s, UgsLaunchInfo *info) {

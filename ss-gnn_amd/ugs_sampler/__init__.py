@@ -385,6 +385,25 @@ class Plan:
                                 edge_src.data_ptr()))
         return edge_index, edge_src
 
+    def step(self, m_per_graph, mode="sample", seed=42, row_begin=0, row_count=None, extra_node_offset=0, out=None, edge_capacity=None):
+        """Walk + fill as one call into edge buffers of a capacity fixed up front (no host read-back in between): returns
+        (nodes [rows,k], edge_ptr [rows+1], edge_index [2,capacity], edge_src [capacity]) as device tensors; edge_ptr[-1] is the
+        number of valid edge entries.  The hot path's step: for batches of small graphs two launches instead of three."""
+        m, seed = _as_c_int(m_per_graph, "m_per_graph"), _as_c_int(seed, "seed")
+        if row_count is None:
+            row_count = self.num_graphs * m - row_begin
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if out is None:
+            cap = int(edge_capacity if edge_capacity is not None else row_count * self.k * (self.k - 1))
+            out = (torch.empty((row_count, self.k), dtype=torch.int64, device=dev), torch.empty((row_count + 1,), dtype=torch.int64, device=dev),
+                   torch.empty((2, cap), dtype=torch.int64, device=dev), torch.empty((cap,), dtype=torch.int64, device=dev))
+        nodes, edge_ptr, edge_index, edge_src = out
+        stream = torch.cuda.current_stream().cuda_stream
+        check(lib.ugs_plan_step(self._h, m, self.k, _BATCH_MODES[mode] if mode in _BATCH_MODES else _EDGE_MODES[mode], int(extra_node_offset),
+                                seed, int(row_begin), int(row_count), stream, nodes.data_ptr(), edge_ptr.data_ptr(), edge_index.data_ptr(),
+                                edge_index.stride(0) if edge_index.size(1) else 0, edge_src.data_ptr()))
+        return nodes, edge_ptr, edge_index, edge_src
+
     def graph_step(self, m_per_graph, mode="sample", row_begin=0, row_count=None, edge_capacity=None):
         """The whole step (walk tiers, scan, fill) for a fixed row range captured once as a HIP graph; `launch(seed)` replays it
         on the current stream into the step's own device tensors.  For launch-bound batches of small graphs."""

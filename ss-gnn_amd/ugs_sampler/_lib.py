@@ -50,6 +50,7 @@ def _load():
         "ugs_plan_info": [vp, C.c_int, i64p, i64p, i64p, i64p, C.POINTER(C.c_int)],
         "ugs_plan_walk": [vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int64, vp, vp, vp, i64p],
         "ugs_plan_fill": [vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, vp, C.c_int64, vp],
+        "ugs_plan_step": [vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int64, vp, vp, vp, vp, C.c_int64, vp],
         "ugs_plan_graph_create": [vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, C.c_int64, vp, C.POINTER(vp)],
         "ugs_plan_graph_launch": [vp, C.c_int, vp],
         "ugs_plan_graph_destroy": [vp],

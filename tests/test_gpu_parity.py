@@ -642,3 +642,62 @@ def test_whole_batch_index_on_a_batch_hashed_in_chunks(product, orc):
     ei3 = ei.copy(); ei3[0, cols - 1] = (ei3[0, cols - 1] + 1) % nv
     calls = [dict(base, edge_index=ei), dict(base, edge_index=ei), dict(base, edge_index=ei2), dict(base, edge_index=ei3), dict(base, edge_index=ei)]
     _same(calls, product, orc, "chunk-hashed batch")
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_step_in_one_call_equals_walk_then_fill(fused, monkeypatch):
+    """Plan.step (walk + fill with the scan folded into the fill kernel for batches of small graphs: tiles of 32 rows in ticket
+    order, decoupled look-back) against the oracle and against walk-then-fill: many consecutive steps on one plan (the ticket
+    counter and the launch epoch move on, no memset in between), row ranges that are no multiple of a tile, a single row, more
+    tiles than one look-back window, every mode; a one-walk-per-wave plan takes the three-launch form behind the same call."""
+    import torch
+    import oracle
+    import ugs_sampler
+    import ugs_workloads as wl
+    if not fused:
+        monkeypatch.setenv("UGS_NO_FUSED_SCAN", "1")
+    torch.cuda.set_device(0)
+    ugs_sampler.clear_cache()
+    cases = [(wl.tu_batch(39, 73, 32), 6, 256), (wl.tu_batch(18, 19, 32), 5, 700), (wl.tu_batch(18, 20, 7), 4, 33)]
+    for (ei, ptr), k, m in cases:
+        G = len(ptr) - 1
+        plan = ugs_sampler.Plan.from_batch(torch.from_numpy(ei), torch.from_numpy(ptr), k)
+        rows_all = G * m
+        ranges = [(0, rows_all), (5, rows_all - 5), (rows_all // 3, 1), (17, min(rows_all - 17, 2049)), (0, 31), (0, 32), (0, 33)]
+        for it, (rb, rc) in enumerate(ranges):
+            mode, seed = ("sample", "graph", "global")[it % 3], 42 + it
+            n2, p2, tot = plan.walk(m, mode, seed, rb, rc)
+            e2, s2 = plan.fill(m, n2, p2, tot, mode, rb)
+            nodes, eptr, eidx, esrc = plan.step(m, mode, seed, rb, rc, edge_capacity=tot + 7)
+            total = int(eptr[-1].item())
+            assert total == tot and torch.equal(nodes, n2) and torch.equal(eptr, p2)
+            assert torch.equal(eidx[:, :total], e2) and torch.equal(esrc[:total], s2), (k, m, rb, rc, mode)
+            if it < 2:
+                want = oracle.sample_batch(ei, ptr, m, k, mode, seed)
+                assert np.array_equal(nodes.cpu().numpy(), np.asarray(want[0])[rb:rb + rc])
+                lo, hi = int(np.asarray(want[2])[rb]), int(np.asarray(want[2])[rb + rc])
+                assert np.array_equal(eidx[:, :total].cpu().numpy(), np.asarray(want[1])[:, lo:hi])
+                assert np.array_equal(esrc[:total].cpu().numpy(), np.asarray(want[4])[lo:hi])
+        if fused:
+            assert plan.last_launch()["kernel"].startswith("ugs_walk_lds<8")
+        plan.close()
+    # capacity below the total: nothing is written past the buffers, edge_ptr still carries the true total
+    (ei, ptr), k, m = cases[0]
+    plan = ugs_sampler.Plan.from_batch(torch.from_numpy(ei), torch.from_numpy(ptr), k)
+    n2, p2, tot = plan.walk(m, "sample", 1)
+    e2, s2 = plan.fill(m, n2, p2, tot, "sample")
+    cap = tot // 2                                              # ld is the row stride AND the capacity: contiguous buffers of exactly `cap` entries
+    guard = torch.full((2 * cap + 128,), -7, dtype=torch.int64, device="cuda")
+    gsrc = torch.full((cap + 64,), -7, dtype=torch.int64, device="cuda")
+    out = plan.step(m, "sample", 1, out=(torch.empty_like(n2), torch.empty_like(p2), guard[:2 * cap].view(2, cap), gsrc[:cap]))
+    assert int(out[1][-1].item()) == tot and torch.equal(out[2], e2[:, :cap]) and torch.equal(out[3], s2[:cap])
+    assert bool((guard[2 * cap:] == -7).all()) and bool((gsrc[cap:] == -7).all())
+    plan.close()
+    # a large graph (one walk per wave, staged edges): the same call, three launches
+    ei, ptr = wl.er_graph(3000, 60000, seed=3)
+    plan = ugs_sampler.Plan.from_batch(torch.from_numpy(ei), torch.from_numpy(ptr), 6)
+    n2, p2, tot = plan.walk(500, "global", 9)
+    e2, s2 = plan.fill(500, n2, p2, tot, "global")
+    nodes, eptr, eidx, esrc = plan.step(500, "global", 9, edge_capacity=tot)
+    assert torch.equal(nodes, n2) and torch.equal(eptr, p2) and torch.equal(eidx, e2) and torch.equal(esrc, s2)
+    plan.close()
