@@ -175,13 +175,6 @@ struct Rng {
     uint64_t s;
     __device__ __forceinline__ void init(uint64_t seed) {
         s = seed ? seed : 1ull;
-#ifdef UGS_V3
-        // the state is wave-uniform with one walk per wave, and the compiler would keep the generator and everything derived from
-        // it on the scalar unit (49 scalar instructions per draw); opaque to the uniformity analysis it stays on the vector unit
-        uint32_t lo = (uint32_t)s, hi = (uint32_t)(s >> 32);
-        asm volatile("" : "+v"(lo), "+v"(hi));
-        s = ((uint64_t)hi << 32) | lo;
-#endif
     }
     __device__ __forceinline__ uint64_t next() {
         uint64_t x = s;
@@ -865,12 +858,8 @@ __device__ __forceinline__ Pick select_lds(const Work<LdsSpace> &ws, const Grp<G
     // (C5: 96 VGPRs + 52 bytes of scratch -> 88 VGPRs, none; 5.68 -> 5.53 ms per 1M walks).
     Grp<GS> g = g_;
     asm volatile("" : "+v"(g.lane));
-#ifdef UGS_V1
     int fs;
     if constexpr (GS == 64) fs = chain_index_below_lanes(c, g_.chain); else fs = chain_index_below<NST>(c);
-#else
-    const int fs = chain_index_below<NST>(c);                                 // the final stage: first chain value >= c
-#endif
     materialise_bits<GS, MAXPER, 0, NST>(ws, g, ((1u << fs) - 1u) & ~((1u << nvalid) - 1u));     // stages nvalid .. fs-1
     nvalid = nvalid > fs ? nvalid : fs;
     return final_from<GS, MAXPER, 0, NST>(ws, g, fs, c, rsel);
@@ -980,11 +969,9 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
         // probe: only `seen` and `slot` are carried round the loop; what happened is read off `seen` afterwards
         uint32_t seen = kKeyMask;                                 // a value no probe returns for a candidate
         STAMP_SUB_BEGIN();
-#ifdef UGS_V4
         if constexpr (GS == 64 && sizeof(typename SP::TW) == 4) {
             if (cand) slot = probe_insert_lds(ws.HK, ws.hmask, slot, step, w, seen);
         } else
-#endif
         if (cand) {
             for (uint32_t it = 0; it <= ws.hmask; ++it) {         // the table is never full
                 seen = atomicCAS(&ws.HK[slot], kEmpty, w | kFresh);
@@ -1014,10 +1001,8 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
             dupm &= ~grp;
         }
         if (inserted) ws.HK[slot] = w;                            // the chunk is over for this key: drop kFresh
-#ifdef UGS_V5
         if constexpr (GS == 64) ecount += in_s ? (w == v ? 1u : 2u) : 0u;       // per lane, summed over the wave at the end of the walk
         else
-#endif
         {   // entries to earlier members count twice (the mirror entry), entries to the scanned vertex itself once
             const uint64_t im = g.ballot(in_s), sm = g.ballot(w == v);
             ecount += 2u * (uint32_t)__popcll(im & ~sm) + (uint32_t)__popcll(im & sm);
@@ -1032,11 +1017,9 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
         SP::sync();
     } else {
         uint32_t seen = kEmpty;
-#ifdef UGS_V4
         if constexpr (GS == 64 && sizeof(typename SP::TW) == 4) {
             if (cand) probe_find_lds(ws.HK, ws.hmask, slot, step, w, seen);
         } else
-#endif
         if (cand) {
             for (uint32_t it = 0; it <= ws.hmask; ++it) {
                 seen = ws.HK[slot];
@@ -1045,10 +1028,8 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
             }
         }
         in_s = (seen & (kKeyMask | kInS)) == (w | kInS);                     // kEmpty (no candidate, or not seen) matches no vertex
-#ifdef UGS_V5
         if constexpr (GS == 64) ecount += in_s ? (w == v ? 1u : 2u) : 0u;
         else
-#endif
         {
             const uint64_t im = g.ballot(in_s), sm = g.ballot(w == v);
             ecount += 2u * (uint32_t)__popcll(im & ~sm) + (uint32_t)__popcll(im & sm);
@@ -1075,14 +1056,10 @@ __device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, c
 // padded row of v (one walk per wave): `e0` = entry `lane` of the row's block, loaded by the caller as soon as v was known.
 // Lane 0 holds the header (degree, CSR position of the first entry), lanes 1.. the first entries; a longer row continues in adj[].
 __device__ __forceinline__ int2 prow_entry(const UgsPlanDev &P, int64_t vrow, int lane) {
-#ifdef UGS_V8
     // the padded rows of a plan span less than 4 GB (ensure_prow), so an entry's byte offset fits 32 bits: one shift-add per lane
     // and the scalar base in the load, instead of 64-bit vector address arithmetic
     const uint32_t off = (((uint32_t)vrow << P.prow_shift) + (uint32_t)lane) << 3;
     return *reinterpret_cast<const int2 *>(reinterpret_cast<const char *>(P.prow) + off);
-#else
-    return P.prow[(vrow << P.prow_shift) + lane];
-#endif
 }
 __device__ __forceinline__ int2 load_prow(const UgsPlanDev &P, int64_t vrow, int lane) {
     int2 e = make_int2(0, 0);
@@ -1102,7 +1079,6 @@ __device__ __forceinline__ bool scan_prow(const Work<SP> &ws, const Grp<64> &g, 
         if (g.lane >= P.prow_first && g.lane <= (int)n0) e0 = prow_entry(P, vrow, g.lane);
     }
     if ((uint32_t)(g.lane - 1) >= n0) e0 = UGS_NO_ENTRY;                        // the header's lane and the lanes behind the row
-#ifdef UGS_V6
     // a row whose every entry could be a new candidate and still fit needs no per-chunk overflow tests (nearly all rows); the
     // others take the guarded chunks, so the walks a tier hands on are exactly those it handed on before
     if (ADD && hcount + deg <= ws.hlimit && c + deg <= ws.cap) {
@@ -1116,7 +1092,6 @@ __device__ __forceinline__ bool scan_prow(const Work<SP> &ws, const Grp<64> &g, 
         }
         return true;
     }
-#endif
     if (n0 && !scan_chunk<64, SP, ADD, STG>(ws, g, v, root_vi, size, c, hcount, ecount, sc, e0, start + (uint32_t)g.lane - 1u)) return false;
     const uint32_t r1 = start + deg;
     for (uint32_t base = start + inl; base < r1; base += 64) {
@@ -1139,19 +1114,29 @@ __device__ __forceinline__ void stage_flush(uint32_t ne, const Grp<64> &g, const
     for (uint32_t j = 0; j < k; ++j) ei = (SV[j] == en.y) ? j : ei;
     const uint32_t es = en.z;
     uint32_t cr = 0u;                                                         // rank of the hit's column among the hits
-    for (uint32_t t = 0; t < ne; ++t) {
-        const uint32_t ct = g.bcast(ecol, (int)t);
-        cr += (ct < ecol || (ct == ecol && t < lane)) ? 1u : 0u;
+    // four hits per trip: the loop control is scalar work per trip; lanes past the hits (and trips past them) compare with a column
+    // that sorts behind every real one, so their contribution is zero without a test
+    const uint32_t ecol_s = mine ? ecol : 0xFFFFFFFFu;
+    for (uint32_t t = 0; t < ne; t += 4) {
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint32_t ct = g.bcast(ecol_s, (int)((t + u) & 63u));
+            cr += (ct < ecol || (ct == ecol && t + u < lane)) ? 1u : 0u;
+        }
     }
     const bool mirror = mine && ei != es;
     const uint32_t ka = es * UGS_STAGE_ENTRIES + cr, kb = ei * UGS_STAGE_ENTRIES + cr;   // all keys are distinct
     const uint32_t kk = (ka << 16) | kb;
     uint32_t ra = 0u, rb = 0u;
-    for (uint32_t t = 0; t < ne; ++t) {
-        const uint32_t kt = g.bcast(kk, (int)t);
-        const uint32_t kat = kt >> 16, kbt = ((kt >> 21) == ((kt >> 5) & 0x7FFu)) ? 0xFFFFu : (kt & 0xFFFFu);   // no mirror: compares false
-        ra += (kat < ka ? 1u : 0u) + (kbt < ka ? 1u : 0u);
-        rb += (kat < kb ? 1u : 0u) + (kbt < kb ? 1u : 0u);
+    const uint32_t kk_s = mine ? kk : 0xFFFFFFFFu;                            // behind every real key, and "no mirror"
+    for (uint32_t t = 0; t < ne; t += 4) {
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint32_t kt = g.bcast(kk_s, (int)((t + u) & 63u));
+            const uint32_t kat = kt >> 16, kbt = ((kt >> 21) == ((kt >> 5) & 0x7FFu)) ? 0xFFFFu : (kt & 0xFFFFu);
+            ra += (kat < ka ? 1u : 0u) + (kbt < ka ? 1u : 0u);
+            rb += (kat < kb ? 1u : 0u) + (kbt < kb ? 1u : 0u);
+        }
     }
     if (mine) out[ra] = make_uint2(ecol, es | (ei << 8));
     if (mirror) out[rb] = make_uint2(ecol, ei | (es << 8));
@@ -1305,9 +1290,7 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
         {   // stages whose candidates all precede position q keep their order
             int keep = 0;
             if constexpr (sizeof(typename SP::TW) == 4) {                     // LDS tiers: the chain values are immediates
-#ifdef UGS_V1
                 if constexpr (GS == 64) keep = chain_index_below_lanes(q + 1u, g_.chain); else
-#endif
                 keep = chain_index_below<nst_of(MAXPER * GS)>(q + 1u);        // number of B[i] <= q
                 keep = keep < nvalid ? keep : nvalid;
             } else {
@@ -1320,7 +1303,6 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
         {   // w is now a member of the sample: flag its hash entry (the group probes GS consecutive slots per round trip)
             const uint32_t step = hash_step(w);
             uint32_t s = (hash_slot(w, ws.hmask) + (uint32_t)g.lane * step) & ws.hmask;
-#ifdef UGS_V2
             // lane i looks at the i-th slot of w's probe sequence; the entry is there (w was a candidate) and almost always among
             // the first GS slots, so the loop is written around that case: read, compare, one scalar test, write
             bool hit = ws.HK[s] == w;                                 // a candidate's entry carries no flag
@@ -1329,17 +1311,8 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
                 hit = ws.HK[s] == w;
             }
             if (hit) ws.HK[s] = w | kInS;
-#else
-            for (uint32_t it = 0; it <= ws.hmask; it += GS) {         // lane i looks at the i-th slot of w's probe sequence
-                const bool hit = ws.HK[s] == w;                       // a candidate's entry carries no flag
-                if (g.any(hit)) { if (hit) ws.HK[s] = w | kInS; break; }
-                s = (s + GS * step) & ws.hmask;
-            }
-#endif
-#ifdef UGS_V7
             if constexpr (GS == 64) SV[size] = w;                     // every lane, same word, same value: no lane-0 mask to set up
             else
-#endif
             if (g.lane == 0) SV[size] = w;
         }
         size += 1;
@@ -1347,9 +1320,7 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
         SP::sync();
         STAMP_END(3);
     }
-#ifdef UGS_V5
     if constexpr (GS == 64) ecount = g.last(g.prefix_incl(ecount));              // the lanes' counts -> the row's
-#endif
     const uint32_t nedges = (size == (uint32_t)k) ? ecount : 0u;                // incomplete rows carry no edges (:219-223)
     // staged hits: fetch their edge columns now, the row's epilogue below runs while the gather is in flight
     bool flush = false;
@@ -1398,9 +1369,7 @@ __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP == 704 ?
     __shared__ __attribute__((aligned(16))) uint32_t lds[GROUPS * Cfg::WORDS];
     Grp<GS> g;
     g.init();
-#ifdef UGS_V1
     if constexpr (GS == 64) g.chain = chain_lane_const<Cfg::NSTAGE>(g.lane);
-#endif
     const int gib = (int)threadIdx.x / GS;
     uint32_t *base = lds + gib * Cfg::WORDS;
     Work<LdsSpace> ws;

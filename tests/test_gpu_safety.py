@@ -214,7 +214,86 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["global_rows"] == 100_000
     # the destination-aware split (default --dst-rows auto): three calibration rounds, the first on the equal split; the ranks' rows cover the batch
     pr, cal = line["per_rank"], line["split_calibration"]
-    assert len(cal) == 3 and cal[0]["rows"] == [50_000, 50_000] and sum(cal[1]["rows"]) == 100_000 and sum(cal[2]["rows"]) == 100_000
+    assert len(cal) == 4 and cal[0]["rows"] == [50_000, 50_000] and sum(cal[1]["rows"]) == 100_000 and sum(cal[2]["rows"]) == 100_000
+    assert cal[3]["split"] in ("derived from the last round", "best measured round") and len(cal[3]["slowest_rank_ms"]) == 3
     assert [p_["rank"] for p_ in pr] == [0, 1] and sum(p_["rows"] for p_ in pr) == 100_000 and line["config"]["rows_per_gpu"] == pr[0]["rows"]
     assert pr[0]["walk_share"] == 80 and pr[1]["walk_share"] == 100 and all(p_["walk_ms"] > 0 for p_ in pr)
     assert line["collate_ms_per_step"] is not None and line["extras"]["weak_scaling"]["global_rows"] == 200_000
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_sharded_qm9_batch_on_one_gpu(world):
+    """BASELINE config 4 (QM9-shaped, k = 5, 32 graphs x 2048 samples = 65 536 rows, "sharded over 8 GPUs") through the multi-rank
+    path of bench.py with 2 and 3 ranks on this GPU: the row ranges cut through graphs (row b = g * m + i: a rank's range starts
+    and ends inside a graph), mode "sample" sends local edge ids as uint8 on the wire, the split is calibrated (and guarded), and
+    rank 0 checks the placement of its own AND the other ranks' rows against the unsharded rows.  The numbers mean nothing."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--rehearse", "--workload", "c4_qm9_b65536",
+                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=380)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == world and line["config"]["global_rows"] == 65_536 and line["config"]["graphs"] == 32
+    pr, cal = line["per_rank"], line["split_calibration"]
+    assert [p_["rank"] for p_ in pr] == list(range(world)) and sum(p_["rows"] for p_ in pr) == 65_536
+    if world == 3:                                                  # m = 2048 rows per graph: no split into three ends on graph boundaries
+        assert any(p_["rows"] % 2048 for p_ in pr[:-1]), "the shards were meant to cut through graphs"
+    assert len(cal) == 4 and all(sum(c_["rows"]) == 65_536 for c_ in cal[:3])
+    assert line["collate_ms_per_step"] is not None
+
+
+@pytest.mark.parametrize("kind", ["general", "device_pass", "handle", "wave_tier"])
+def test_a_plan_and_its_twin_on_two_streams_give_the_oracle_rows(kind, monkeypatch):
+    """Plan.twin() (ugs_plan_twin: the same device arrays, private scratch) with consecutive seeds alternating between the plan on
+    one stream and the twin on another -- plans of the general path, of the device batch pass (descriptors uploaded asynchronously:
+    the twin must not run ahead of them), of a handle, and of a one-walk-per-wave tier (padded rows built before the twin copies
+    the arrays); then the owner is released and the twin keeps sampling.  Every row against the oracle."""
+    import torch
+    import oracle
+    import ugs_sampler
+    import ugs_workloads as wl
+    torch.cuda.set_device(0)
+    ugs_sampler.clear_cache()
+    k, m = 5, 40
+    if kind == "wave_tier":
+        ei, ptr = wl.er_graph(4000, 70000, seed=11)
+        k, m = 6, 300
+    else:
+        ei, ptr = wl.tu_batch(18, 19, 12, dataset_seed=7)
+    monkeypatch.setenv("UGS_DEVICE_BATCH", "1" if kind == "device_pass" else "0")
+    if kind == "handle":
+        ei, ptr = np.ascontiguousarray(ei[:, :38]), ptr[:2]          # the first graph's columns
+        h = ugs_sampler.create_preproc(torch.from_numpy(ei), 18, k)
+        plan = ugs_sampler.Plan.from_handle(h, k)
+        pre = oracle.Preproc(ei, 18, k)
+        want = lambda seed: pre.sample(m, k, "local", 0, seed)                                  # noqa: E731
+        mode = "local"
+    else:
+        plan = ugs_sampler.Plan.from_batch(torch.from_numpy(ei), torch.from_numpy(ptr), k)
+        want = lambda seed: [np.asarray(x) for i, x in enumerate(oracle.sample_batch(ei, ptr, m, k, "sample", seed)) if i != 3]   # noqa: E731
+        mode = "sample"
+    twin = plan.twin()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    for i in range(8):
+        with torch.cuda.stream(streams[i % 2]):
+            outs.append((plan if i % 2 == 0 else twin).sample_rows(m, mode, 100 + i))
+    torch.cuda.synchronize()
+    plan.close()                                                    # the owner goes first: the arrays live while the twin does
+    for i in range(8, 12):
+        with torch.cuda.stream(streams[i % 2]):
+            outs.append(twin.sample_rows(m, mode, 100 + i))
+    torch.cuda.synchronize()
+    for i, (nodes, eidx, eptr, esrc) in enumerate(outs):
+        w = want(100 + i)
+        assert np.array_equal(nodes.cpu().numpy(), np.asarray(w[0])) and np.array_equal(eidx.cpu().numpy(), np.asarray(w[1])), (kind, i)
+        assert np.array_equal(eptr.cpu().numpy(), np.asarray(w[2])) and np.array_equal(esrc.cpu().numpy(), np.asarray(w[3])), (kind, i)
+    twin.close()
+    if kind == "handle":
+        pre.close()
+        ugs_sampler.destroy_preproc(h)

@@ -34,5 +34,27 @@ out = {"_note": __doc__.split("usage:")[0].strip(),
                                      "with the header, the 4th only for rows that reach into it), the root record costs a 64-byte sector or two, every staged hit's edge "
                                      "column one sector, and the walk writes ~14 staged 8-byte items per row beside nodes and counts",
             "source": sys.argv[1]}}
+# what binds the kernel is instruction issue, not HBM: the same passes give the instruction mix per walk and how busy the issue ports are
+c = summ[k]
+def cnt(name):
+    return c[name]["mean"] if name in c else None
+if cnt("SQ_INSTS_VALU") is not None and cnt("SQ_BUSY_CYCLES") is not None:
+    simd_quads = cnt("SQ_BUSY_CYCLES") / 32.0 / 4.0 * 1024.0          # SQ_BUSY_CYCLES is summed over 32 shader engines; 1024 SIMDs; quad-cycles
+    issue = {"instructions_per_walk": round(cnt("SQ_INSTS") / rows, 1) if cnt("SQ_INSTS") else None,
+             "valu_per_walk": round(cnt("SQ_INSTS_VALU") / rows, 1), "salu_per_walk": round(cnt("SQ_INSTS_SALU") / rows, 1),
+             "lds_per_walk": round(cnt("SQ_INSTS_LDS") / rows, 1) if cnt("SQ_INSTS_LDS") else None,
+             "branch_per_walk": round(cnt("SQ_INSTS_BRANCH") / rows, 1) if cnt("SQ_INSTS_BRANCH") else None,
+             "valu_busy_share_of_simd_quad_cycles": round(cnt("SQ_ACTIVE_INST_VALU") / simd_quads, 3) if cnt("SQ_ACTIVE_INST_VALU") else None,
+             "scalar_busy_share_of_simd_quad_cycles": round(cnt("SQ_ACTIVE_INST_SCA") / simd_quads, 3) if cnt("SQ_ACTIVE_INST_SCA") else None,
+             "wave_cycles_waiting": round(cnt("SQ_WAIT_ANY") / cnt("SQ_WAVE_CYCLES"), 3) if cnt("SQ_WAIT_ANY") and cnt("SQ_WAVE_CYCLES") else None,
+             "wave_cycles_issue_stalled": round(cnt("SQ_WAIT_INST_ANY") / cnt("SQ_WAVE_CYCLES"), 3) if cnt("SQ_WAIT_INST_ANY") and cnt("SQ_WAVE_CYCLES") else None,
+             "marginal_cost_wave_cycles": {"scalar": 12.4, "vector_4B": 7.2, "vector_8B": 9.9, "source": "profiles/r04_pad_probe.txt: 448 dummy instructions per walk of each kind"}}
+    out[wl]["issue"] = issue
+try:                                   # keep the other workloads' entries
+    old = json.load(open("profiles/pmc_traffic.json"))
+    old.update(out)
+    out = old
+except Exception:
+    pass
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out[wl], indent=1))
