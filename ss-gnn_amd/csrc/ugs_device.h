@@ -117,11 +117,9 @@ struct UgsFillArgs {
     const int64_t *ulist;      // with staging: the rows the row-reading kernel still has to do
     const uint32_t *ucount;
     // scan folded into the fill (small-batch step, ugs_fill_scan): the kernel turns the walk's per-row counts into edge_ptr itself --
-    // tiles of 32 rows in ticket order, a tile's offset by decoupled look-back over the tiles in front of it
+    // tiles of 32 rows, a tile's offset by looking back over the published sums of the tiles in front of it
     int64_t *edge_ptr_out;              // [row_count + 1], written by the kernel (NULL: edge_ptr above is read)
     unsigned long long *tile_state;     // [tiles]: epoch << 40 | flag << 38 | value (flag 1: the tile's sum, 2: the sum of all tiles up to it)
-    unsigned long long *ticket;         // tile hand-out counter, never reset: the host knows its value before the launch (ticket_base)
-    unsigned long long ticket_base;
     uint32_t epoch;                     // names the launch: states of earlier launches are stale, no memset between calls
     uint32_t pad2;
 };
@@ -164,8 +162,8 @@ hipError_t ugs_launch_batch_roots(const int64_t *d_ptr, const int64_t *d_rstart,
                                   const UgsBpMissIn *h_in, UgsBpMissOut *h_out, int64_t misses, int k, UgsRootRec *d_roots, int2 *d_via, hipStream_t s);
 hipError_t ugs_launch_scan(const uint32_t *counts, int64_t rows, int64_t *edge_ptr, int64_t *block_tmp, hipStream_t s);
 hipError_t ugs_launch_fill(const UgsFillArgs &a, int wide, int device_cus, hipStream_t s, UgsLaunchInfo *info);
-// scan + fill in one launch (8-lane tier, rows read from their adjacency): grid and tickets the launch will consume
-hipError_t ugs_launch_fill_scan(const UgsFillArgs &a, int device_cus, hipStream_t s, UgsLaunchInfo *info, int64_t *tickets_used);
+// scan + fill in one launch (8-lane tier, rows read from their adjacency)
+hipError_t ugs_launch_fill_scan(const UgsFillArgs &a, int device_cus, hipStream_t s, UgsLaunchInfo *info);
 int64_t ugs_fill_scan_tiles(int64_t rows);
 int64_t ugs_scan_tmp_words(int64_t rows);
 int64_t ugs_global_ws_words(int64_t gcap, int64_t gbcap, int64_t gpcap, int64_t ghs);

@@ -508,10 +508,9 @@ struct ugs_plan {
     // edges staged by the last walk (UgsWalkArgs::stage) and the call they belong to: a fill of exactly those rows into/from
     // the same nodes buffer expands them; any other fill reads the adjacency rows again
     PoolBuf stage, ulist, work;   // work: 3 x u64 next-item counters (one per walk launch of a call)
-    // scan folded into the fill (ugs_plan_step, ugs_fill_scan): [ticket counter | pad to 64 B | one state word per tile of 32 rows].
-    // The counter is never reset (the host mirrors it), states carry the launch's epoch: no memset between steps.
+    // scan folded into the fill (ugs_plan_step, ugs_fill_scan): one state word per tile of 32 rows; the states carry the launch's epoch:
+    // no memset between steps
     PoolBuf tiles;
-    unsigned long long tile_tickets = 0;
     uint32_t tile_epoch = 0;
     // stream order between calls: a plan's scratch is reused by every call, so a call on another stream than the previous one
     // first waits (on the device) for that call's last kernel
@@ -1883,12 +1882,12 @@ int ugs_plan_step(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
     std::lock_guard<std::mutex> lk(plan->mu);
     if (int rc = plan_enter(plan, s)) return rc;
     const int64_t tiles = ugs_fill_scan_tiles(row_count);
-    const size_t need = 64 + (size_t)tiles * sizeof(unsigned long long);
+    const size_t need = (size_t)tiles * sizeof(unsigned long long);
     const bool fresh = !plan->tiles.p || plan->tiles.bytes < need;
     if (fresh) { if (int rc = ensure(plan->tiles, std::max<size_t>(need, 4096), plan->device, plan)) return rc; }
     if (fresh || ++plan->tile_epoch >= (1u << 24)) {        // a buffer from the pool holds anything; a wrapped epoch would meet its own old states
         HIP_TRY(hipMemsetAsync(plan->tiles.p, 0, plan->tiles.bytes, s));
-        plan->tile_tickets = 0; plan->tile_epoch = 1;
+        plan->tile_epoch = 1;
     }
     UgsFillArgs a{};
     a.plan = plan->dev;
@@ -1898,13 +1897,10 @@ int ugs_plan_step(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
     a.nodes = d_nodes; a.edge_ptr = d_edge_ptr; a.edge_ptr_out = d_edge_ptr;
     a.edge_index = d_edge_index; a.ld = ld; a.edge_src = d_edge_src;
     a.counts = static_cast<const uint32_t *>(plan->counts.p);
-    a.ticket = static_cast<unsigned long long *>(plan->tiles.p);
-    a.tile_state = a.ticket + 8;
-    a.ticket_base = plan->tile_tickets; a.epoch = plan->tile_epoch;
-    int64_t used = 0;
+    a.tile_state = static_cast<unsigned long long *>(plan->tiles.p);
+    a.epoch = plan->tile_epoch;
     HIP_TRY(ev_begin(plan, 2, s));
-    HIP_TRY(ugs_launch_fill_scan(a, plan->cus, s, &plan->last_fill, &used));
-    plan->tile_tickets += (unsigned long long)used;
+    HIP_TRY(ugs_launch_fill_scan(a, plan->cus, s, &plan->last_fill));
     HIP_TRY(ev_end(plan, s));
     return plan_leave(plan, s);
 }

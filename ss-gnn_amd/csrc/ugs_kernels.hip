@@ -1106,38 +1106,54 @@ __device__ __forceinline__ bool scan_prow(const Work<SP> &ws, const Grp<64> &g, 
 // End of a complete walk: the <= 32 hits become the row's directed items (hit at position p of row s pointing to member i:
 // item s->i, and its mirror i->s unless i == s), ranked in the output order -- source index, then CSR position, and inside
 // one row CSR position order is edge-column order (the symmetrised CSR is built in column order; equal columns only for
-// the two identical entries of a self loop).  One lane per hit, the others' keys come through v_readlane as scalars.
-__device__ __forceinline__ void stage_flush(uint32_t ne, const Grp<64> &g, const uint32_t *SV, uint32_t k, uint4 en, uint32_t ecol, uint2 *out) {
+// the two identical entries of a self loop).  One lane per hit.
+//   cr   = rank of the hit's column among the hits: one compare per other hit, whose column arrives as a scalar (v_readlane).
+//          Columns tie only between the two entries of a self loop; the tie-breaking second compare runs only if the row has a
+//          self hit at all (wave-uniform test).
+//   rank = items with a smaller (source, cr) key.  The keys are small and distinct, so they are COUNTED, not compared: every item
+//          sets bit cr of its source's word in LDS (MS[source], one atomic OR each), and its rank is the population of the words of
+//          the smaller sources plus that of the lower bits of its own word -- k word reads and popcounts per lane instead of a
+//          second loop over the hits with four compares each (round 4: 400 -> ~230 instructions per walk for this routine).
+// MS: 32 words of LDS scratch -- the hit list's own memory, the hits are in registers by now.
+__device__ __forceinline__ void stage_flush(uint32_t ne, const Grp<64> &g, const uint32_t *SV, uint32_t k, uint4 en, uint32_t ecol, uint2 *out,
+                                            uint32_t *MS) {
     const uint32_t lane = (uint32_t)g.lane;
     const bool mine = lane < ne;
+    if (lane < UGS_KMAX) MS[lane] = 0u;
     uint32_t ei = 0u;                                                         // local index of the member the hit points to
     for (uint32_t j = 0; j < k; ++j) ei = (SV[j] == en.y) ? j : ei;
     const uint32_t es = en.z;
-    uint32_t cr = 0u;                                                         // rank of the hit's column among the hits
-    // four hits per trip: the loop control is scalar work per trip; lanes past the hits (and trips past them) compare with a column
-    // that sorts behind every real one, so their contribution is zero without a test
+    uint32_t cr = 0u;
+    // four hits per trip (the loop control is scalar work per trip); lanes past the hits hold a column that sorts behind every real one
     const uint32_t ecol_s = mine ? ecol : 0xFFFFFFFFu;
-    for (uint32_t t = 0; t < ne; t += 4) {
+    if (g.any(mine && ei == es)) {                                            // a self hit: columns may tie
+        for (uint32_t t = 0; t < ne; t += 4) {
 #pragma unroll
-        for (uint32_t u = 0; u < 4; ++u) {
-            const uint32_t ct = g.bcast(ecol_s, (int)((t + u) & 63u));
-            cr += (ct < ecol || (ct == ecol && t + u < lane)) ? 1u : 0u;
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t ct = g.bcast(ecol_s, (int)((t + u) & 63u));
+                cr += (ct < ecol || (ct == ecol && t + u < lane)) ? 1u : 0u;
+            }
+        }
+    } else {
+        for (uint32_t t = 0; t < ne; t += 4) {
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) cr += g.bcast(ecol_s, (int)((t + u) & 63u)) < ecol ? 1u : 0u;
         }
     }
     const bool mirror = mine && ei != es;
-    const uint32_t ka = es * UGS_STAGE_ENTRIES + cr, kb = ei * UGS_STAGE_ENTRIES + cr;   // all keys are distinct
-    const uint32_t kk = (ka << 16) | kb;
-    uint32_t ra = 0u, rb = 0u;
-    const uint32_t kk_s = mine ? kk : 0xFFFFFFFFu;                            // behind every real key, and "no mirror"
-    for (uint32_t t = 0; t < ne; t += 4) {
-#pragma unroll
-        for (uint32_t u = 0; u < 4; ++u) {
-            const uint32_t kt = g.bcast(kk_s, (int)((t + u) & 63u));
-            const uint32_t kat = kt >> 16, kbt = ((kt >> 21) == ((kt >> 5) & 0x7FFu)) ? 0xFFFFu : (kt & 0xFFFFu);
-            ra += (kat < ka ? 1u : 0u) + (kbt < ka ? 1u : 0u);
-            rb += (kat < kb ? 1u : 0u) + (kbt < kb ? 1u : 0u);
-        }
+    const uint32_t bit = 1u << (cr & 31u);
+    LdsSpace::sync();                                                         // MS is zero
+    if (mine) atomicOr(&MS[es], bit);
+    if (mirror) atomicOr(&MS[ei], bit);
+    LdsSpace::sync();
+    uint32_t ra = 0u, rb = 0u, ma = 0u, mb = 0u;
+    for (uint32_t j = 0; j < k; ++j) {
+        const uint32_t mj = MS[j], pc = (uint32_t)__popc(mj);
+        ra += j < es ? pc : 0u; rb += j < ei ? pc : 0u;
+        ma = j == es ? mj : ma; mb = j == ei ? mj : mb;
     }
+    ra += (uint32_t)__popc(ma & (bit - 1u));
+    rb += (uint32_t)__popc(mb & (bit - 1u));
     if (mine) out[ra] = make_uint2(ecol, es | (ei << 8));
     if (mirror) out[rb] = make_uint2(ecol, ei | (es << 8));
 }
@@ -1220,8 +1236,12 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
 #define UGS_PAD1 asm volatile("s_mov_b32 %0, 0x12345678" : "=s"(pad_));
 #elif UGS_PAD == 3
 #define UGS_PAD1 asm volatile("v_mov_b32_e32 %0, 0" : "=v"(pad_));
-#else
+#elif UGS_PAD == 4
 #define UGS_PAD1 asm volatile("v_mov_b32_e64 %0, 0" : "=v"(pad_));
+#elif UGS_PAD == 5      /* a conditional branch that is not taken */
+#define UGS_PAD1 asm volatile("s_cmp_eq_u32 0, 0\ns_cbranch_scc0 ugs_pad_%=\nugs_pad_%=:" : "=s"(pad_) : : "scc");
+#else                   /* a taken branch (to the next instruction) */
+#define UGS_PAD1 asm volatile("s_branch ugs_pad_%=\nugs_pad_%=:" : "=s"(pad_));
 #endif
 #define UGS_PAD8 UGS_PAD1 UGS_PAD1 UGS_PAD1 UGS_PAD1 UGS_PAD1 UGS_PAD1 UGS_PAD1 UGS_PAD1
             UGS_PAD8 UGS_PAD8 UGS_PAD8 UGS_PAD8 UGS_PAD8 UGS_PAD8 UGS_PAD8 UGS_PAD8
@@ -1336,7 +1356,7 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
     // one word per row: the edge-entry count and, in its top bit, whether the row's items are staged (one store instead of two)
     if (g.lane == 0) a.counts[row_rel] = nedges | (flush ? UGS_COUNT_STAGED : 0u);
     if (a.stage) {                                                               // staging is on for this call
-        if constexpr (STG) { if (flush) stage_flush(sc.ne, g, SV, (uint32_t)k, en, ecol, a.stage + row_rel * UGS_STAGE_ITEMS); }
+        if constexpr (STG) { if (flush) stage_flush(sc.ne, g, SV, (uint32_t)k, en, ecol, a.stage + row_rel * UGS_STAGE_ITEMS, reinterpret_cast<uint32_t *>(EL)); }
         if (g.lane == 0 && !flush && nedges != 0u) a.ulist[atomicAdd(a.ucount, 1u)] = row_rel;
     }
     STAMP_END(5);
@@ -1735,13 +1755,14 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
 }
 
 // The small-batch step in two launches instead of three: the fill kernel of the 8-lane tier with the exclusive scan of the walk's
-// per-row counts folded in (reference semantics of edge_ptr: src/sampler.cpp:249-287).  A block takes tiles of 32 consecutive rows in
-// TICKET order (so every tile in front of a running tile has been started), publishes its tile's sum, and finds the sum of all
-// tiles in front of it by decoupled look-back: one wave reads the states of the 64 preceding tiles at a time, adds the sums up
-// to the nearest tile that already knows its own prefix, and publishes its prefix in turn.  A tile publishes its sum before it
-// waits for anything, and tile 0 knows its prefix at once, so the chain cannot stall; tiles are uniform and short (32 counts), so
-// a look-back rarely waits at all.  One 64-bit word per tile carries launch epoch, flag and value together: no ordering between
-// separate words is needed, and no memset between launches (stale epochs read as "not yet").
+// per-row counts folded in (reference semantics of edge_ptr: src/sampler.cpp:249-287).  A block takes tiles of 32 consecutive rows,
+// publishes its tile's sum, and finds the sum of all tiles in front of it by looking back: one wave reads the states of the 64
+// preceding tiles at a time and adds their sums up to the nearest tile that already knows its own prefix, then publishes its prefix
+// in turn.  NOTHING WAITS: a tile whose sum is not published yet is summed from the counts themselves (they are final: the walk
+// kernels are over), so no tile depends on another block being scheduled -- the published words only save reading -- and tiles need no
+// hand-out order (a first version took tickets from one counter: 2048 atomics on one address cost the QM9-shaped step 40 us).
+// One 64-bit word per tile carries launch epoch, flag and value together: no ordering between separate words is needed, and no
+// memset between launches (stale epochs read as "not published").
 constexpr int kFsEpochShift = 40, kFsFlagShift = 38;
 constexpr unsigned long long kFsValueMask = (1ull << kFsFlagShift) - 1ull;
 __device__ __forceinline__ unsigned long long fs_pack(uint32_t epoch, uint32_t flag, unsigned long long v) {
@@ -1756,14 +1777,13 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long x)
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void ugs_fill_scan(UgsFillArgs a) {
     constexpr int GS = 8, GROUPS = BLOCK / GS;
-    static_assert(GROUPS <= 64, "one wave scans a tile's counts");
+    static_assert(GROUPS == 32, "a tile is 32 rows: eight 16-byte loads of counts");
     __shared__ uint32_t sv_all[GROUPS * UGS_KMAX];
     __shared__ uint32_t ps_all[GROUPS * (UGS_KMAX + 1)];
     __shared__ int64_t r0_all[GROUPS * UGS_KMAX];
     __shared__ uint32_t cnt_sh[GROUPS];
     __shared__ unsigned long long excl_sh[GROUPS];
     __shared__ unsigned long long front_sh;
-    __shared__ unsigned long long tile_sh;
     Grp<GS> g;
     g.init();
     const int gib = (int)threadIdx.x / GS;
@@ -1772,12 +1792,8 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill_scan(UgsFillArgs a) {
     int64_t *R0 = r0_all + gib * UGS_KMAX;
     const UgsPlanDev &P = a.plan;
     const int k = a.k;
-    const unsigned long long ntiles = (unsigned long long)((a.row_count + GROUPS - 1) / GROUPS);
-    for (;;) {
-        if (threadIdx.x == 0) tile_sh = atomicAdd(a.ticket, 1ull) - a.ticket_base;
-        __syncthreads();
-        const unsigned long long tile = tile_sh;
-        if (tile >= ntiles) break;
+    const long long ntiles = (long long)((a.row_count + GROUPS - 1) / GROUPS);
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row_rel = (int64_t)tile * GROUPS + gib;
         const bool in = row_rel < a.row_count;
         const uint32_t c = in ? (a.counts[row_rel] & ~UGS_COUNT_STAGED) : 0u;
@@ -1791,33 +1807,37 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill_scan(UgsFillArgs a) {
             for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
             const unsigned long long S = (unsigned long long)__shfl(incl, 63, 64);
             if (lane < GROUPS) excl_sh[lane] = (unsigned long long)(incl - x);
+            if (lane == 0) __hip_atomic_store(&a.tile_state[tile], fs_pack(a.epoch, tile == 0 ? 2u : 1u, S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned long long front = 0ull;
-            if (tile == 0ull) {
-                if (lane == 0) __hip_atomic_store(&a.tile_state[0], fs_pack(a.epoch, 2u, S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                if (lane == 0) __hip_atomic_store(&a.tile_state[tile], fs_pack(a.epoch, 1u, S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                long long base = (long long)tile - 1;
-                for (;;) {
-                    const long long idx = base - lane;
-                    unsigned long long st = fs_pack(a.epoch, 2u, 0ull);                    // in front of tile 0: prefix 0
-                    if (idx >= 0) st = __hip_atomic_load(&a.tile_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t fl = (uint32_t)(st >> kFsFlagShift) & 3u;
-                    const bool ok = (uint32_t)(st >> kFsEpochShift) == a.epoch && fl != 0u;
-                    const uint64_t pm = __ballot(ok && fl == 2u), bad = __ballot(!ok);
-                    const unsigned long long v = st & kFsValueMask;
-                    if (pm) {
-                        const int L = __ffsll((long long)pm) - 1;                          // nearest tile that knows its prefix
-                        if (bad & ((1ull << L) - 1ull)) { __builtin_amdgcn_s_sleep(1); continue; }   // a nearer tile has not published yet
-                        front += wave_sum_u64(lane <= L ? v : 0ull);
-                        break;
+            for (long long base = tile - 1; base >= 0; base -= 64) {
+                const long long idx = base - lane;
+                unsigned long long st = fs_pack(a.epoch, 2u, 0ull);                       // in front of tile 0: prefix 0
+                if (idx >= 0) st = __hip_atomic_load(&a.tile_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t fl = (uint32_t)(st >> kFsFlagShift) & 3u;
+                const bool ok = (uint32_t)(st >> kFsEpochShift) == a.epoch && fl != 0u;
+                unsigned long long v = st & kFsValueMask;
+                if (!ok) {                                                                // not published yet: that tile's sum from its counts
+                    const uint4 *q = reinterpret_cast<const uint4 *>(a.counts + idx * GROUPS);   // 128-byte aligned (pool buffers are), 32 counts
+                    const int64_t left = a.row_count - idx * GROUPS;                      // >= 1
+                    v = 0ull;
+#pragma unroll
+                    for (int t = 0; t < GROUPS / 4; ++t) {
+                        if ((int64_t)(4 * t + 3) < left) { const uint4 w = q[t]; v += (w.x & ~UGS_COUNT_STAGED) + (unsigned long long)(w.y & ~UGS_COUNT_STAGED) + (w.z & ~UGS_COUNT_STAGED) + (unsigned long long)(w.w & ~UGS_COUNT_STAGED); }
+                        else for (int u = 0; u < 4; ++u) if ((int64_t)(4 * t + u) < left) v += a.counts[idx * GROUPS + 4 * t + u] & ~UGS_COUNT_STAGED;
                     }
-                    if (bad) { __builtin_amdgcn_s_sleep(1); continue; }
-                    front += wave_sum_u64(v);
-                    base -= 64;
                 }
-                if (lane == 0) __hip_atomic_store(&a.tile_state[tile], fs_pack(a.epoch, 2u, front + S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint64_t pm = __ballot(ok && fl == 2u);
+                if (pm) {                                                                 // nearest tile that knows its prefix: done
+                    const int L = __ffsll((long long)pm) - 1;
+                    front += wave_sum_u64(lane <= L ? v : 0ull);
+                    break;
+                }
+                front += wave_sum_u64(v);
             }
-            if (lane == 0) front_sh = front;
+            if (lane == 0) {
+                if (tile != 0) __hip_atomic_store(&a.tile_state[tile], fs_pack(a.epoch, 2u, front + S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                front_sh = front;
+            }
         }
         __syncthreads();
         const int64_t e0 = (int64_t)(front_sh + excl_sh[gib]);
@@ -1977,7 +1997,7 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill_staged(UgsFillArgs a) {
 
 int64_t ugs_fill_scan_tiles(int64_t rows) { return (rows + 31) / 32; }
 
-hipError_t ugs_launch_fill_scan(const UgsFillArgs &a, int cus, hipStream_t s, UgsLaunchInfo *info, int64_t *tickets_used) {
+hipError_t ugs_launch_fill_scan(const UgsFillArgs &a, int cus, hipStream_t s, UgsLaunchInfo *info) {
     if (cus <= 0) cus = 256;
     constexpr int BLOCK = 256, GROUPS = 32;
     const int64_t tiles = (a.row_count + GROUPS - 1) / GROUPS;
@@ -1986,7 +2006,6 @@ hipError_t ugs_launch_fill_scan(const UgsFillArgs &a, int cus, hipStream_t s, Ug
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL((ugs_fill_scan<BLOCK>), dim3((unsigned)grid), dim3(BLOCK), 0, s, a);
     if (info) { info->name = "ugs_fill_scan<8>"; info->grid = (int)grid; info->block = BLOCK; info->lds_bytes = GROUPS * UGS_KMAX * 4; }
-    if (tickets_used) *tickets_used = tiles + grid;             // every block ends on the first ticket beyond the tiles
     return hipGetLastError();
 }
 
