@@ -627,6 +627,9 @@ def main():
         except Exception as e:   # noqa: BLE001
             out["cpu_baseline_calibration"] = {"error": str(e)[:200]}
     if world == 1:
+        hv = (out.get("drop_in_call") or {}).get("host_visible_subgraphs_per_s")
+        if hv:      # SURVEY.md 8(d)'s metric -- wall time of the sample_batch call with host-visible outputs -- beside `value` (inputs and outputs resident in HBM)
+            out["value_host_visible"] = hv
         try:
             out["summary"] = summary_block(out, args.workload)      # LAST key: the driver's record keeps the tail of the line
         except Exception as e:   # noqa: BLE001

@@ -119,7 +119,7 @@ struct UgsFillArgs {
     // scan folded into the fill (small-batch step, ugs_fill_scan): the kernel turns the walk's per-row counts into edge_ptr itself --
     // tiles of 32 rows, a tile's offset by looking back over the published sums of the tiles in front of it
     int64_t *edge_ptr_out;              // [row_count + 1], written by the kernel (NULL: edge_ptr above is read)
-    unsigned long long *tile_state;     // [tiles]: epoch << 40 | flag << 38 | value (flag 1: the tile's sum, 2: the sum of all tiles up to it)
+    unsigned long long *tile_state;     // [tiles + ceil(tiles / 64)]: epoch << 40 | value -- a tile's sum; behind them the sums of the groups of 64 tiles
     uint32_t epoch;                     // names the launch: states of earlier launches are stale, no memset between calls
     uint32_t pad2;
 };
@@ -153,14 +153,17 @@ int64_t ugs_batch_pass_fused_work();             /* the limit in force: UGS_BP_F
 hipError_t ugs_launch_batch_pass(const int64_t *d_src, const int64_t *d_dst, int64_t E, const int64_t *d_ptr, int64_t G, int k,
                                  int32_t *d_owner, uint32_t *d_cnt_jminc_jmax, const int64_t *d_rstart, int64_t *d_rowptr, int2 *d_adj,
                                  int2 *d_adjf, int32_t *d_vrank, unsigned long long *d_bump, unsigned long long bump_base, uint32_t epoch, void *h_back,
-                                 hipStream_t s);
+                                 unsigned long long *d_done, unsigned long long done_base, hipStream_t s);
 // graphs of a device-built plan the LRU does not know (cold path): the rest of their preprocessing on the device (ugs_bp_roots)
 #define UGS_BATCH_ROOTS_MAX_N 1024     /* larger unknown graphs are preprocessed on the host, as before */
 struct UgsBpMissIn { int32_t g; int32_t pad; int64_t roots_off; int64_t via_off; };           // arena offsets (elements) reserved by the host
 struct UgsBpMissOut { int32_t level, n_viable, nonzero, max_deg; double Z, sb_deg; };
 hipError_t ugs_launch_batch_roots(const int64_t *d_ptr, const int64_t *d_rstart, const int64_t *d_rowptr, const int2 *d_adj, const int32_t *d_vrank,
-                                  const UgsBpMissIn *h_in, UgsBpMissOut *h_out, int64_t misses, int k, UgsRootRec *d_roots, int2 *d_via, hipStream_t s);
-hipError_t ugs_launch_scan(const uint32_t *counts, int64_t rows, int64_t *edge_ptr, int64_t *block_tmp, hipStream_t s);
+                                  const UgsBpMissIn *h_in, UgsBpMissOut *h_out, int64_t misses, int k, UgsRootRec *d_roots, int2 *d_via,
+                                  unsigned long long *d_done, unsigned long long done_base, uint32_t *h_done, uint32_t epoch, hipStream_t s);
+// h_total / h_flag (pinned host memory, or NULL): the kernel also hands the total to the host and signals with `epoch`
+hipError_t ugs_launch_scan(const uint32_t *counts, int64_t rows, int64_t *edge_ptr, int64_t *block_tmp, hipStream_t s, int64_t *h_total = nullptr,
+                           uint32_t *h_flag = nullptr, uint32_t epoch = 0);
 hipError_t ugs_launch_fill(const UgsFillArgs &a, int wide, int device_cus, hipStream_t s, UgsLaunchInfo *info);
 // scan + fill in one launch (8-lane tier, rows read from their adjacency)
 hipError_t ugs_launch_fill_scan(const UgsFillArgs &a, int device_cus, hipStream_t s, UgsLaunchInfo *info);

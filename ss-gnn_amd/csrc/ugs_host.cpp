@@ -27,7 +27,7 @@
 #include <vector>
 
 struct ugs_plan;
-namespace { void plan_unref(ugs_plan *p); void arena_release(int dev, int64_t roots_off, int64_t n_roots, int64_t via_off, int64_t n_via); }
+namespace { void plan_unref(ugs_plan *p); void arena_release(int dev, int64_t roots_off, int64_t n_roots, int64_t via_off, int64_t n_via); void pin_slot_put(char *p); }
 
 // launcher of the epsilon_uniform kernels (ugs_eps.hip)
 struct UgsEpsLaunch {
@@ -512,6 +512,10 @@ struct ugs_plan {
     // no memset between steps
     PoolBuf tiles;
     uint32_t tile_epoch = 0;
+    // job path: the scan kernel hands the edge total to the host through 16 bytes of pinned memory (total, epoch word) and the host
+    // polls the word instead of copying the total back behind a stream wait (wait_signal)
+    char *pin_slot = nullptr;
+    uint32_t pin_epoch = 0;
     // stream order between calls: a plan's scratch is reused by every call, so a call on another stream than the previous one
     // first waits (on the device) for that call's last kernel
     hipEvent_t last_ev = nullptr;
@@ -718,6 +722,7 @@ void destroy_plan(ugs_plan *p) {
     if (p->blob_buf.p) pool_put(p->blob_buf); else if (p->blob) (void)hipFree(p->blob);
     pool_put(p->counts); pool_put(p->ovf1); pool_put(p->ovf2); pool_put(p->ovfcnt); pool_put(p->scantmp);
     pool_put(p->stage); pool_put(p->ulist); pool_put(p->work); pool_put(p->tiles);
+    pin_slot_put(p->pin_slot);
     if (p->prow.p) { if (p->prow_pooled) pool_put(p->prow); else (void)hipFree(p->prow.p); p->prow = PoolBuf(); }
     if (p->gws.p) { (void)hipFree(p->gws.p); p->gws = PoolBuf(); }
     ugs_plan *owner = p->twin_of;
@@ -1047,6 +1052,7 @@ struct RootArena {
     hipEvent_t desc_ev[2] = {nullptr, nullptr}; int desc_slot = 0;
     unsigned long long *d_bump = nullptr;                               // device counter handing out CSR space to the graphs of a pass (never reset)
     unsigned long long bump_host = 0;                                   // its value before the next pass
+    unsigned long long done_host = 0;                                   // likewise the blocks-done counter (d_bump + 1) behind the kernels' completion signal
     uint32_t epoch = 0;                                                 // names a pass: written to the flag word by a graph beyond the limits
     std::mutex call_mu;                                                 // one device pass at a time per device (shared staging)
 };
@@ -1125,11 +1131,13 @@ int graph_dev_roots(Graph &g, int dev, RootArena *ar, hipStream_t s, Graph::DevR
 }
 
 // UGS_DEVICE_BATCH: 0 = never, 1 = whenever applicable, unset = whenever applicable and the batch has at least
-// kBatchPassMinCols columns.  The chain upload -> kernel -> keys back costs ~25 us of latencies whatever the size.  Around 1200
-// columns (MUTAG- / QM9-shaped batches of 32 graphs) that is a tie with the host's own pass + plan assembly for host-visible
-// outputs (0.15 against 0.145 ms, 0.73 against 0.715 ms per call) and 20 us behind it with device outputs (0.195 against 0.175 ms);
-// at 4672 columns (PROTEINS-shaped) the pass wins both (0.276 against 0.31 ms, 0.19 against 0.22 ms).
-constexpr int64_t kBatchPassMinCols = 2048;
+// kBatchPassMinCols columns.  The chain upload -> kernel -> keys back costs ~20 us of latencies whatever the size (round 4: the host
+// polls the kernel's completion word instead of waiting on the stream, -5 us).  Around 1200 columns (MUTAG- / QM9-shaped batches of
+// 32 graphs) that now ties with the host's own pass + plan assembly for host-visible outputs (0.115 against 0.114 ms, 0.699 against
+// 0.698 ms per call) and wins or ties with device outputs (0.163 against 0.179 ms, 0.111 against 0.111 ms); at 4672 columns
+// (PROTEINS-shaped) the pass wins both (0.265 against 0.278 ms).  Below ~1000 columns the host's pass over the columns is a few
+// microseconds and no chain of device latencies can tie with it: the default keeps such batches on the host.
+constexpr int64_t kBatchPassMinCols = 1024;
 int device_batch_mode() {
     const char *e = std::getenv("UGS_DEVICE_BATCH");
     if (e && e[0] == '0') return 0;
@@ -1138,6 +1146,37 @@ int device_batch_mode() {
 }
 
 constexpr int kBatchNotApplicable = 1;      // positive: not an error code of the C ABI
+
+// 64-byte slots of pinned host memory, handed out from slabs that live as long as the process
+std::mutex g_pin_mu;
+std::vector<char *> &g_pin_free = *new std::vector<char *>();
+char *pin_slot_get() {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (g_pin_free.empty()) {
+        void *slab = nullptr;
+        if (hipHostMalloc(&slab, 64 * 256, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        std::memset(slab, 0, 64 * 256);
+        for (int i = 255; i >= 0; --i) g_pin_free.push_back(static_cast<char *>(slab) + 64 * i);
+    }
+    char *p = g_pin_free.back();
+    g_pin_free.pop_back();
+    std::memset(p, 0, 64);                      // whatever the slot's last owner's kernels wrote (they are long over)
+    return p;
+}
+std::atomic<uint32_t> g_pin_epoch{0};           // one sequence for all plans: a slot changes hands, its signal values never repeat
+void pin_slot_put(char *p) { if (p) { std::lock_guard<std::mutex> lk(g_pin_mu); g_pin_free.push_back(p); } }
+
+// Wait for a kernel that signals its end by writing `want` to a word in pinned host memory (ugs_batch.hip: bp_signal_done): polling the
+// word returns ~5 us earlier than hipStreamSynchronize on this stack (tools/sync_probe.hip: 5.9 against 10.9 us for an empty kernel).
+// The budget bounds the spin: a kernel that faulted never signals, and the stream wait behind the spin reports its error.
+hipError_t wait_signal(const volatile uint32_t *word, uint32_t want, hipStream_t s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 0;; ++it) {
+        if (*word == want) { std::atomic_thread_fence(std::memory_order_acquire); return hipSuccess; }
+        if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+    }
+    return hipStreamSynchronize(s);
+}
 std::atomic<int64_t> g_bp_plans{0}, g_bp_fallbacks{0};     // plans built by the device pass / calls it handed to the general path
 
 // Returns UGS_OK with *plan_out set, kBatchNotApplicable (the caller takes the general path; the LRU has not been touched, or
@@ -1150,8 +1189,8 @@ int device_batch_plan(const int64_t *src, const int64_t *dst, int64_t E, const i
     std::lock_guard<std::mutex> call_lk(ar->call_mu);
     // pinned staging, one buffer: [src E | dst E | ptr G+1 | rstart G] goes up in ONE copy, [keys G | cnt G | jminc G | jmax G | flag] comes
     // back in one, two descriptor slots go up behind the LRU replay
-    const size_t up_words = (size_t)(2 * E + 2 * G + 1), back_bytes = (size_t)G * 20 + 8, desc_bytes = (size_t)G * sizeof(UgsGraphDesc);
-    const size_t miss_bytes = (size_t)G * (sizeof(UgsBpMissIn) + sizeof(UgsBpMissOut));
+    const size_t up_words = (size_t)(2 * E + 2 * G + 1), back_bytes = (size_t)G * 20 + 16, desc_bytes = (size_t)G * sizeof(UgsGraphDesc);
+    const size_t miss_bytes = (size_t)G * (sizeof(UgsBpMissIn) + sizeof(UgsBpMissOut)) + 16;
     const size_t st_back = align_up(up_words * 8), st_desc = align_up(st_back + back_bytes), st_miss = align_up(st_desc + 2 * align_up(desc_bytes)),
                  st_total = align_up(st_miss + miss_bytes);
     // the staging's layout depends on this call's E and G: a descriptor copy of an earlier call (asynchronous, from a region placed by
@@ -1163,6 +1202,7 @@ int device_batch_plan(const int64_t *src, const int64_t *dst, int64_t E, const i
         const size_t want = std::max<size_t>(st_total * 2, 1 << 18);
         if (hipHostMalloc(&ar->pinned, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return kBatchNotApplicable; }
         ar->pinned_bytes = want;
+        std::memset(ar->pinned, 0, want);
     }
     auto *hostv = static_cast<int64_t *>(ar->pinned);                   // src | dst | ptr | rstart
     int64_t *h_ptr = hostv + 2 * E, *h_rstart = h_ptr + (G + 1);
@@ -1196,16 +1236,20 @@ int device_batch_plan(const int64_t *src, const int64_t *dst, int64_t E, const i
     char *h_back = static_cast<char *>(ar->pinned) + st_back;
     const uint32_t epoch = ++ar->epoch ? ar->epoch : ++ar->epoch;       // never 0
     *reinterpret_cast<volatile uint32_t *>(h_back + (size_t)G * 20) = 0u;
+    *reinterpret_cast<volatile uint32_t *>(h_back + (size_t)G * 20 + 4) = 0u;     // the completion word: the staging's layout moves with E and G, so the
+                                                                                   // word may hold anything an earlier call left there -- e.g. a column count equal to this epoch
     hipError_t e = hipMemcpyAsync(d_src, hostv, up_words * 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = ugs_launch_batch_pass(d_src, d_dst, E, d_ptr, G, k, reinterpret_cast<int32_t *>(base + o_owner), reinterpret_cast<uint32_t *>(base + o_cnt),
                                                    d_ptr + (G + 1), reinterpret_cast<int64_t *>(base + o_row), reinterpret_cast<int2 *>(base + o_adj),
                                                    reinterpret_cast<int2 *>(base + o_adjf), reinterpret_cast<int32_t *>(base + o_vrank), ar->d_bump, ar->bump_host,
-                                                   epoch, h_back, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) {       // the counter's value is unknown now: start again from zero
-        (void)hipMemset(ar->d_bump, 0, 8); ar->bump_host = 0;
+                                                   epoch, h_back, ar->d_bump + 1, ar->done_host, s);
+    if (e == hipSuccess) e = wait_signal(reinterpret_cast<volatile uint32_t *>(h_back + (size_t)G * 20 + 4), epoch, s);
+    if (e != hipSuccess) {       // the counters' values are unknown now: start again from zero
+        (void)hipDeviceSynchronize();
+        (void)hipMemset(ar->d_bump, 0, 16); ar->bump_host = 0; ar->done_host = 0;
         return bail(fail_hip(e, "device batch pass"));
     }
+    ar->done_host += (unsigned long long)G;
     const double t_pass = lap();
     const auto *h_keys = reinterpret_cast<const unsigned long long *>(h_back);
     const auto *h_cnt = reinterpret_cast<const uint32_t *>(h_back + (size_t)G * 8), *h_jminc = h_cnt + G, *h_jmax = h_jminc + G;
@@ -1213,6 +1257,7 @@ int device_batch_plan(const int64_t *src, const int64_t *dst, int64_t E, const i
         unsigned long long used = 0;
         for (int64_t g = 0; g < G; ++g) used += 2ull * h_cnt[g];
         if (h_jmax[G] == epoch) {                                        // a graph beyond the limits of the pass: which blocks allocated is not known
+            (void)hipStreamSynchronize(s);                              // the signal came from the last block's thread 0: let the kernel retire before its counter is rewritten
             (void)hipMemset(ar->d_bump, 0, 8); ar->bump_host = 0;
             return bail(kBatchNotApplicable);
         }
@@ -1332,10 +1377,19 @@ int device_batch_plan(const int64_t *src, const int64_t *dst, int64_t E, const i
         auto *h_in = reinterpret_cast<UgsBpMissIn *>(static_cast<char *>(ar->pinned) + st_miss);
         auto *h_out = reinterpret_cast<UgsBpMissOut *>(h_in + G);
         for (size_t i = 0; i < pend.size(); ++i) h_in[i] = UgsBpMissIn{(int32_t)pend[i].g, 0, pend[i].roots_off, pend[i].via_off};
+        auto *h_rdone = reinterpret_cast<uint32_t *>(h_out + G);
+        *reinterpret_cast<volatile uint32_t *>(h_rdone) = 0u;
         e = ugs_launch_batch_roots(d_ptr, d_ptr + (G + 1), reinterpret_cast<const int64_t *>(base + o_row), reinterpret_cast<const int2 *>(base + o_adj),
-                                   reinterpret_cast<const int32_t *>(base + o_vrank), h_in, h_out, (int64_t)pend.size(), k, ar->roots, ar->via, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) { give_up(); return fail_hip(e, "device batch pass: root records"); }
+                                   reinterpret_cast<const int32_t *>(base + o_vrank), h_in, h_out, (int64_t)pend.size(), k, ar->roots, ar->via,
+                                   ar->d_bump + 1, ar->done_host, h_rdone, epoch, s);
+        if (e == hipSuccess) e = wait_signal(h_rdone, epoch, s);
+        if (e != hipSuccess) {
+            (void)hipDeviceSynchronize();
+            (void)hipMemset(ar->d_bump, 0, 16); ar->bump_host = 0; ar->done_host = 0;
+            give_up();
+            return fail_hip(e, "device batch pass: root records");
+        }
+        ar->done_host += (unsigned long long)pend.size();
         for (size_t i = 0; i < pend.size(); ++i) {
             Graph &gg = *pend[i].gr;
             const UgsBpMissOut &o = h_out[i];
@@ -1707,7 +1761,7 @@ int ugs_plan_info(const ugs_plan *plan, int k, int64_t *num_graphs, int64_t *num
 
 static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int seed, const uint64_t *d_seed_ptr,
                           int64_t row_begin, int64_t row_count, void *stream, int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *total_edges_host,
-                          bool *defer_scan = nullptr);
+                          bool *defer_scan = nullptr, bool poll_total = false);
 
 int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int seed, int64_t row_begin,
                   int64_t row_count, void *stream, int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *total_edges_host) {
@@ -1718,7 +1772,7 @@ int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
 // their adjacency, nothing is staged), no capture in progress -- the scan launch is left out and *defer_scan set.
 static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int seed, const uint64_t *d_seed_ptr,
                           int64_t row_begin, int64_t row_count, void *stream, int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *total_edges_host,
-                          bool *defer_scan) {
+                          bool *defer_scan, bool poll_total) {
     if (defer_scan) *defer_scan = false;
     if (!plan) return fail(UGS_E_BAD_ARG, "plan is null");
     if (k < 1) return fail(UGS_E_BAD_ARG, "k must be >= 1");
@@ -1822,10 +1876,30 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
         last = 2;
     }
     const bool defer = defer_scan && !total_edges_host && tc.first == UGS_TIER_S && !capturing(s) && std::getenv("UGS_NO_FUSED_SCAN") == nullptr;
+    // the library's own jobs (poll_total): the scan kernel hands the total to the host and the host polls for it -- the caller of the job
+    // API gets its outputs from later operations on the same stream, so nothing else needs the stream to be idle here.  Not while rows
+    // may have been handed on (the overflow counters are read back with the total) and not under UGS_DEBUG.
+    bool polled = false;
+    if (poll_total && total_edges_host && !may_overflow && !debug_on() && !capturing(s) && !defer_scan) {
+        if (!plan->pin_slot) plan->pin_slot = pin_slot_get();
+        polled = plan->pin_slot != nullptr;
+    }
     if (defer) *defer_scan = true;
-    else HIP_TRY(ugs_launch_scan(static_cast<const uint32_t *>(plan->counts.p), row_count, d_edge_ptr, static_cast<int64_t *>(plan->scantmp.p), s));
+    else if (polled) {
+        uint32_t ep = g_pin_epoch.fetch_add(1) + 1;
+        if (ep == 0) ep = g_pin_epoch.fetch_add(1) + 1;
+        plan->pin_epoch = ep;
+        HIP_TRY(ugs_launch_scan(static_cast<const uint32_t *>(plan->counts.p), row_count, d_edge_ptr, static_cast<int64_t *>(plan->scantmp.p), s,
+                                reinterpret_cast<int64_t *>(plan->pin_slot), reinterpret_cast<uint32_t *>(plan->pin_slot + 8), ep));
+    } else HIP_TRY(ugs_launch_scan(static_cast<const uint32_t *>(plan->counts.p), row_count, d_edge_ptr, static_cast<int64_t *>(plan->scantmp.p), s));
     HIP_TRY(ev_end(plan, s));
     if (int rc = plan_leave(plan, s)) return rc;
+    if (polled) {
+        HIP_TRY(wait_signal(reinterpret_cast<volatile uint32_t *>(plan->pin_slot + 8), plan->pin_epoch, s));
+        *total_edges_host = *reinterpret_cast<volatile int64_t *>(plan->pin_slot);
+        plan->last_overflow = 0;
+        return UGS_OK;
+    }
     if (total_edges_host) {
         uint32_t h[4] = {0, 0, 0, 0};
         int64_t tot = 0;
@@ -1882,7 +1956,7 @@ int ugs_plan_step(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
     std::lock_guard<std::mutex> lk(plan->mu);
     if (int rc = plan_enter(plan, s)) return rc;
     const int64_t tiles = ugs_fill_scan_tiles(row_count);
-    const size_t need = (size_t)tiles * sizeof(unsigned long long);
+    const size_t need = (size_t)(tiles + (tiles + 63) / 64) * sizeof(unsigned long long);       // a word per tile, a word per group of 64 tiles
     const bool fresh = !plan->tiles.p || plan->tiles.bytes < need;
     if (fresh) { if (int rc = ensure(plan->tiles, std::max<size_t>(need, 4096), plan->device, plan)) return rc; }
     if (fresh || ++plan->tile_epoch >= (1u << 24)) {        // a buffer from the pool holds anything; a wrapped epoch would meet its own old states
@@ -2156,7 +2230,8 @@ int begin_common(ugs_plan *plan, int m, int k, int mode, int64_t extra, int seed
     int rc = pool_get((size_t)(j->rows * k + j->rows + 1) * sizeof(int64_t), dc.id, j->nodes);
     if (!rc) {
         j->d_eptr = static_cast<int64_t *>(j->nodes.p) + j->rows * k;
-        rc = ugs_plan_walk(plan, m, k, mode, extra, seed, 0, j->rows, dc.stream, static_cast<int64_t *>(j->nodes.p), j->d_eptr, &j->total);
+        rc = plan_walk_impl(plan, m, k, mode, extra, seed, nullptr, 0, j->rows, dc.stream, static_cast<int64_t *>(j->nodes.p), j->d_eptr, &j->total,
+                            nullptr, true);
     }
     if (rc) { free_job(j); return rc; }
     *job_out = j;

@@ -815,13 +815,16 @@ __device__ __forceinline__ void materialise_bits(const Work<LdsSpace> &ws, const
     }
 }
 
-template <int GS, int MAXPER, int STAGE, int NST>
+// the final stage's variant by a binary decision tree over the stage index [LO, HI] (a chain of `fs == STAGE` tests costs the late,
+// expensive steps four taken branches before their final starts; a taken branch is 18 wave-cycles)
+template <int GS, int MAXPER, int LO, int HI>
 __device__ __forceinline__ Pick final_from(const Work<LdsSpace> &ws, const Grp<GS> &g, int fs, uint32_t c, uint32_t rsel) {
-    if constexpr (STAGE < NST) {
-        if (fs == STAGE) return final_at<GS, MAXPER, STAGE>(ws, g, c, rsel);
-        return final_from<GS, MAXPER, STAGE + 1, NST>(ws, g, fs, c, rsel);
+    if constexpr (LO == HI) {
+        return final_at<GS, MAXPER, LO>(ws, g, c, rsel);
     } else {
-        return final_at<GS, MAXPER, NST>(ws, g, c, rsel);
+        constexpr int MID = (LO + HI + 1) / 2;
+        if (fs >= MID) return final_from<GS, MAXPER, MID, HI>(ws, g, fs, c, rsel);
+        return final_from<GS, MAXPER, LO, MID - 1>(ws, g, fs, c, rsel);
     }
 }
 
@@ -860,7 +863,8 @@ __device__ __forceinline__ Pick select_lds(const Work<LdsSpace> &ws, const Grp<G
     asm volatile("" : "+v"(g.lane));
     int fs;
     if constexpr (GS == 64) fs = chain_index_below_lanes(c, g_.chain); else fs = chain_index_below<NST>(c);
-    materialise_bits<GS, MAXPER, 0, NST>(ws, g, ((1u << fs) - 1u) & ~((1u << nvalid) - 1u));     // stages nvalid .. fs-1
+    const uint32_t need = ((1u << fs) - 1u) & ~((1u << nvalid) - 1u);        // stages nvalid .. fs-1
+    if (need) materialise_bits<GS, MAXPER, 0, NST>(ws, g, need);             // (nothing to bring up to date in a third of the steps: one test instead of NST)
     nvalid = nvalid > fs ? nvalid : fs;
     return final_from<GS, MAXPER, 0, NST>(ws, g, fs, c, rsel);
 }
@@ -1106,27 +1110,22 @@ __device__ __forceinline__ bool scan_prow(const Work<SP> &ws, const Grp<64> &g, 
 // End of a complete walk: the <= 32 hits become the row's directed items (hit at position p of row s pointing to member i:
 // item s->i, and its mirror i->s unless i == s), ranked in the output order -- source index, then CSR position, and inside
 // one row CSR position order is edge-column order (the symmetrised CSR is built in column order; equal columns only for
-// the two identical entries of a self loop).  One lane per hit.
-//   cr   = rank of the hit's column among the hits: one compare per other hit, whose column arrives as a scalar (v_readlane).
-//          Columns tie only between the two entries of a self loop; the tie-breaking second compare runs only if the row has a
-//          self hit at all (wave-uniform test).
-//   rank = items with a smaller (source, cr) key.  The keys are small and distinct, so they are COUNTED, not compared: every item
-//          sets bit cr of its source's word in LDS (MS[source], one atomic OR each), and its rank is the population of the words of
-//          the smaller sources plus that of the lower bits of its own word -- k word reads and popcounts per lane instead of a
-//          second loop over the hits with four compares each (round 4: 400 -> ~230 instructions per walk for this routine).
-// MS: 32 words of LDS scratch -- the hit list's own memory, the hits are in registers by now.
-__device__ __forceinline__ void stage_flush(uint32_t ne, const Grp<64> &g, const uint32_t *SV, uint32_t k, uint4 en, uint32_t ecol, uint2 *out,
-                                            uint32_t *MS) {
+// the two identical entries of a self loop).  One lane per hit, the others' keys come through v_readlane as scalars, four hits
+// per trip (the loop control is scalar work per trip; lanes past the hits hold keys that sort behind every real one, so the extra
+// compares of the last trip add nothing).  Columns tie only between the two entries of a self loop: the tie-breaking second
+// compare of the column ranks runs only when the row has a self hit at all (a wave-uniform test).
+// (Round 4 also measured item ranks by COUNTING -- every item sets bit cr of its source's word in LDS, a rank is the population of
+// the smaller sources' words plus the lower bits of its own: ~170 instructions fewer per walk, but three more LDS round trips at
+// the very end of the walk: 5.06 against 4.94 ms per 1M walks, not kept.)
+__device__ __forceinline__ void stage_flush(uint32_t ne, const Grp<64> &g, const uint32_t *SV, uint32_t k, uint4 en, uint32_t ecol, uint2 *out) {
     const uint32_t lane = (uint32_t)g.lane;
     const bool mine = lane < ne;
-    if (lane < UGS_KMAX) MS[lane] = 0u;
-    uint32_t ei = 0u;                                                         // local index of the member the hit points to
+    uint32_t ei = 0u;
     for (uint32_t j = 0; j < k; ++j) ei = (SV[j] == en.y) ? j : ei;
     const uint32_t es = en.z;
     uint32_t cr = 0u;
-    // four hits per trip (the loop control is scalar work per trip); lanes past the hits hold a column that sorts behind every real one
     const uint32_t ecol_s = mine ? ecol : 0xFFFFFFFFu;
-    if (g.any(mine && ei == es)) {                                            // a self hit: columns may tie
+    if (g.any(mine && ei == es)) {
         for (uint32_t t = 0; t < ne; t += 4) {
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) {
@@ -1141,19 +1140,19 @@ __device__ __forceinline__ void stage_flush(uint32_t ne, const Grp<64> &g, const
         }
     }
     const bool mirror = mine && ei != es;
-    const uint32_t bit = 1u << (cr & 31u);
-    LdsSpace::sync();                                                         // MS is zero
-    if (mine) atomicOr(&MS[es], bit);
-    if (mirror) atomicOr(&MS[ei], bit);
-    LdsSpace::sync();
-    uint32_t ra = 0u, rb = 0u, ma = 0u, mb = 0u;
-    for (uint32_t j = 0; j < k; ++j) {
-        const uint32_t mj = MS[j], pc = (uint32_t)__popc(mj);
-        ra += j < es ? pc : 0u; rb += j < ei ? pc : 0u;
-        ma = j == es ? mj : ma; mb = j == ei ? mj : mb;
+    const uint32_t ka = es * UGS_STAGE_ENTRIES + cr, kb = ei * UGS_STAGE_ENTRIES + cr;
+    const uint32_t kk = (ka << 16) | kb;
+    uint32_t ra = 0u, rb = 0u;
+    const uint32_t kk_s = mine ? kk : 0xFFFFFFFFu;
+    for (uint32_t t = 0; t < ne; t += 4) {
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint32_t kt = g.bcast(kk_s, (int)((t + u) & 63u));
+            const uint32_t kat = kt >> 16, kbt = ((kt >> 21) == ((kt >> 5) & 0x7FFu)) ? 0xFFFFu : (kt & 0xFFFFu);
+            ra += (kat < ka ? 1u : 0u) + (kbt < ka ? 1u : 0u);
+            rb += (kat < kb ? 1u : 0u) + (kbt < kb ? 1u : 0u);
+        }
     }
-    ra += (uint32_t)__popc(ma & (bit - 1u));
-    rb += (uint32_t)__popc(mb & (bit - 1u));
     if (mine) out[ra] = make_uint2(ecol, es | (ei << 8));
     if (mirror) out[rb] = make_uint2(ecol, ei | (es << 8));
 }
@@ -1356,7 +1355,7 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
     // one word per row: the edge-entry count and, in its top bit, whether the row's items are staged (one store instead of two)
     if (g.lane == 0) a.counts[row_rel] = nedges | (flush ? UGS_COUNT_STAGED : 0u);
     if (a.stage) {                                                               // staging is on for this call
-        if constexpr (STG) { if (flush) stage_flush(sc.ne, g, SV, (uint32_t)k, en, ecol, a.stage + row_rel * UGS_STAGE_ITEMS, reinterpret_cast<uint32_t *>(EL)); }
+        if constexpr (STG) { if (flush) stage_flush(sc.ne, g, SV, (uint32_t)k, en, ecol, a.stage + row_rel * UGS_STAGE_ITEMS); }
         if (g.lane == 0 && !flush && nedges != 0u) a.ulist[atomicAdd(a.ucount, 1u)] = row_rel;
     }
     STAMP_END(5);
@@ -1544,8 +1543,15 @@ __global__ __launch_bounds__(kScanBlock) void ugs_scan_block_sums(int64_t *block
     }
 }
 
+// the thread that writes the total may also hand it to the host: total, fence, then the launch's epoch into a word of pinned host memory
+// (the host polls the word: ugs_host.cpp wait_signal)
+struct ScanSignal { int64_t *h_total; uint32_t *h_flag; uint32_t epoch; };
+__device__ __forceinline__ void scan_signal(const ScanSignal &sg, int64_t total) {
+    if (sg.h_total) { *sg.h_total = total; __threadfence_system(); *(volatile uint32_t *)sg.h_flag = sg.epoch; }
+}
+
 __global__ __launch_bounds__(kScanBlock) void ugs_scan_final(const uint32_t *counts, int64_t rows, const int64_t *block_offs,
-                                                             int64_t *edge_ptr) {
+                                                             int64_t *edge_ptr, ScanSignal sg) {
     __shared__ int64_t sh[kScanBlock / 64];
     const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanPer;
     uint32_t v[kScanPer];
@@ -1556,13 +1562,13 @@ __global__ __launch_bounds__(kScanBlock) void ugs_scan_final(const uint32_t *cou
     int64_t ex = block_excl_scan(s, &tot, sh) + (block_offs ? block_offs[blockIdx.x] : 0);
 #pragma unroll
     for (int j = 0; j < kScanPer; ++j) { if (base + j < rows) edge_ptr[base + j] = ex; ex += v[j]; }
-    if (rows - 1 >= base && rows - 1 < base + kScanPer) edge_ptr[rows] = ex;   // owner of the last row writes the total
+    if (rows - 1 >= base && rows - 1 < base + kScanPer) { edge_ptr[rows] = ex; scan_signal(sg, ex); }   // owner of the last row writes the total
 }
 
 // Two launches instead of three for up to 4096 tiles (8M rows): every block of the final pass sums the tile totals in front of
 // its own tile itself (at most 16 loads per thread and one block reduction; no flags, no waiting)
 __global__ __launch_bounds__(kScanBlock) void ugs_scan_final_sum(const uint32_t *counts, int64_t rows, const int64_t *tile_sums,
-                                                                 int64_t *edge_ptr) {
+                                                                 int64_t *edge_ptr, ScanSignal sg) {
     __shared__ int64_t sh[kScanBlock / 64];
     int64_t before = 0, front;
     for (int64_t i = threadIdx.x; i < (int64_t)blockIdx.x; i += kScanBlock) before += tile_sums[i];
@@ -1576,12 +1582,12 @@ __global__ __launch_bounds__(kScanBlock) void ugs_scan_final_sum(const uint32_t 
     int64_t ex = block_excl_scan(s, &tot, sh) + front;
 #pragma unroll
     for (int j = 0; j < kScanPer; ++j) { if (base + j < rows) edge_ptr[base + j] = ex; ex += v[j]; }
-    if (rows - 1 >= base && rows - 1 < base + kScanPer) edge_ptr[rows] = ex;   // owner of the last row writes the total
+    if (rows - 1 >= base && rows - 1 < base + kScanPer) { edge_ptr[rows] = ex; scan_signal(sg, ex); }   // owner of the last row writes the total
 }
 
 // single-block variant for small row counts (one launch instead of three): 1024 threads, 8192 rows per round
 constexpr int kScanWide = 1024;
-__global__ __launch_bounds__(kScanWide) void ugs_scan_small(const uint32_t *counts, int64_t rows, int64_t *edge_ptr) {
+__global__ __launch_bounds__(kScanWide) void ugs_scan_small(const uint32_t *counts, int64_t rows, int64_t *edge_ptr, ScanSignal sg) {
     __shared__ int64_t sh[kScanWide / 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int64_t carry = 0;
@@ -1605,7 +1611,7 @@ __global__ __launch_bounds__(kScanWide) void ugs_scan_small(const uint32_t *coun
         for (int j = 0; j < kScanPer; ++j) { if (base + j < rows) edge_ptr[base + j] = ex; ex += v[j]; }
         carry += tot;
     }
-    if (threadIdx.x == 0) edge_ptr[rows] = carry;
+    if (threadIdx.x == 0) { edge_ptr[rows] = carry; scan_signal(sg, carry); }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1755,23 +1761,36 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
 }
 
 // The small-batch step in two launches instead of three: the fill kernel of the 8-lane tier with the exclusive scan of the walk's
-// per-row counts folded in (reference semantics of edge_ptr: src/sampler.cpp:249-287).  A block takes tiles of 32 consecutive rows,
-// publishes its tile's sum, and finds the sum of all tiles in front of it by looking back: one wave reads the states of the 64
-// preceding tiles at a time and adds their sums up to the nearest tile that already knows its own prefix, then publishes its prefix
-// in turn.  NOTHING WAITS: a tile whose sum is not published yet is summed from the counts themselves (they are final: the walk
-// kernels are over), so no tile depends on another block being scheduled -- the published words only save reading -- and tiles need no
-// hand-out order (a first version took tickets from one counter: 2048 atomics on one address cost the QM9-shaped step 40 us).
-// One 64-bit word per tile carries launch epoch, flag and value together: no ordering between separate words is needed, and no
-// memset between launches (stale epochs read as "not published").
-constexpr int kFsEpochShift = 40, kFsFlagShift = 38;
-constexpr unsigned long long kFsValueMask = (1ull << kFsFlagShift) - 1ull;
-__device__ __forceinline__ unsigned long long fs_pack(uint32_t epoch, uint32_t flag, unsigned long long v) {
-    return ((unsigned long long)epoch << kFsEpochShift) | ((unsigned long long)flag << kFsFlagShift) | (v & kFsValueMask);
-}
+// per-row counts folded in (reference semantics of edge_ptr: src/sampler.cpp:249-287).  A block takes tiles of 32 consecutive rows and
+// publishes its tile's sum; the last tile of every GROUP of 64 tiles adds the group's sums up and publishes that too.  A tile's offset
+// is then two short reads: the sums of the groups in front of its own (one word per 2048 rows) and the sums of the tiles in front of
+// it inside its group (at most 63 words) -- no chain from tile to tile, whatever the number of tiles.  (Version one handed tiles out
+// by tickets from one counter: 2048 atomics on one address, 61 us for the QM9-shaped batch.  Version two looked back tile by tile
+// to the nearest published prefix: with every tile of a small batch starting at once nobody has a prefix yet, and the last tile read
+// all 2047 sums in front of it, 32-40 us.)  NOTHING DEPENDS ON ANOTHER BLOCK BEING SCHEDULED: a tile sum that is not published yet
+// is recomputed from the counts themselves (they are final: the walk kernels are over); a group sum is waited for a bounded number
+// of polls and then recomputed from its tiles.  One 64-bit word per sum carries the launch's epoch beside the value: stale epochs
+// read as "not published", so a step needs no memset.
+constexpr int kFsEpochShift = 40;
+constexpr unsigned long long kFsValueMask = (1ull << kFsEpochShift) - 1ull;
+__device__ __forceinline__ unsigned long long fs_pack(uint32_t epoch, unsigned long long v) { return ((unsigned long long)epoch << kFsEpochShift) | (v & kFsValueMask); }
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long x) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) x += (unsigned long long)__shfl_xor((long long)x, d, 64);
     return x;
+}
+// sum of tile `idx` (a full tile: it has a successor) for a lane: its published word, or the 32 counts (128-byte aligned: pool buffers)
+__device__ __forceinline__ unsigned long long fs_tile_sum(const UgsFillArgs &a, long long idx) {
+    const unsigned long long st = __hip_atomic_load(&a.tile_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(st >> kFsEpochShift) == a.epoch) return st & kFsValueMask;
+    const uint4 *q = reinterpret_cast<const uint4 *>(a.counts + idx * 32);
+    unsigned long long v = 0ull;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const uint4 w = q[t];
+        v += (unsigned long long)(w.x & ~UGS_COUNT_STAGED) + (w.y & ~UGS_COUNT_STAGED) + (w.z & ~UGS_COUNT_STAGED) + (w.w & ~UGS_COUNT_STAGED);
+    }
+    return v;
 }
 
 template <int BLOCK>
@@ -1793,6 +1812,7 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill_scan(UgsFillArgs a) {
     const UgsPlanDev &P = a.plan;
     const int k = a.k;
     const long long ntiles = (long long)((a.row_count + GROUPS - 1) / GROUPS);
+    unsigned long long *group_state = a.tile_state + ntiles;             // one word per group of 64 tiles, behind the tiles' words
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row_rel = (int64_t)tile * GROUPS + gib;
         const bool in = row_rel < a.row_count;
@@ -1807,37 +1827,38 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill_scan(UgsFillArgs a) {
             for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
             const unsigned long long S = (unsigned long long)__shfl(incl, 63, 64);
             if (lane < GROUPS) excl_sh[lane] = (unsigned long long)(incl - x);
-            if (lane == 0) __hip_atomic_store(&a.tile_state[tile], fs_pack(a.epoch, tile == 0 ? 2u : 1u, S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned long long front = 0ull;
-            for (long long base = tile - 1; base >= 0; base -= 64) {
-                const long long idx = base - lane;
-                unsigned long long st = fs_pack(a.epoch, 2u, 0ull);                       // in front of tile 0: prefix 0
-                if (idx >= 0) st = __hip_atomic_load(&a.tile_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t fl = (uint32_t)(st >> kFsFlagShift) & 3u;
-                const bool ok = (uint32_t)(st >> kFsEpochShift) == a.epoch && fl != 0u;
-                unsigned long long v = st & kFsValueMask;
-                if (!ok) {                                                                // not published yet: that tile's sum from its counts
-                    const uint4 *q = reinterpret_cast<const uint4 *>(a.counts + idx * GROUPS);   // 128-byte aligned (pool buffers are), 32 counts
-                    const int64_t left = a.row_count - idx * GROUPS;                      // >= 1
-                    v = 0ull;
-#pragma unroll
-                    for (int t = 0; t < GROUPS / 4; ++t) {
-                        if ((int64_t)(4 * t + 3) < left) { const uint4 w = q[t]; v += (w.x & ~UGS_COUNT_STAGED) + (unsigned long long)(w.y & ~UGS_COUNT_STAGED) + (w.z & ~UGS_COUNT_STAGED) + (unsigned long long)(w.w & ~UGS_COUNT_STAGED); }
-                        else for (int u = 0; u < 4; ++u) if ((int64_t)(4 * t + u) < left) v += a.counts[idx * GROUPS + 4 * t + u] & ~UGS_COUNT_STAGED;
-                    }
+            if (lane == 0) __hip_atomic_store(&a.tile_state[tile], fs_pack(a.epoch, S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long grp = tile >> 6, g0 = grp << 6;
+            // the tiles in front of this one inside its group
+            const long long idx = tile - 1 - lane;
+            unsigned long long front = wave_sum_u64(idx >= g0 ? fs_tile_sum(a, idx) : 0ull);
+            if ((tile & 63) == 63 && lane == 0)                              // the group is complete with this tile: its sum for the tiles behind it
+                __hip_atomic_store(&group_state[grp], fs_pack(a.epoch, front + S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the groups in front of this tile's group
+            for (long long gb = grp - 1; gb >= 0; gb -= 64) {
+                const long long sidx = gb - lane;
+                unsigned long long st = fs_pack(a.epoch, 0ull);
+                bool ok = true;
+                if (sidx >= 0) {
+                    st = __hip_atomic_load(&group_state[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (uint32_t)(st >> kFsEpochShift) == a.epoch;
                 }
-                const uint64_t pm = __ballot(ok && fl == 2u);
-                if (pm) {                                                                 // nearest tile that knows its prefix: done
-                    const int L = __ffsll((long long)pm) - 1;
-                    front += wave_sum_u64(lane <= L ? v : 0ull);
-                    break;
+                for (int spin = 0; spin < 64 && __ballot(!ok); ++spin) {      // the group's last tile publishes within a microsecond or two of the launch
+                    __builtin_amdgcn_s_sleep(8);
+                    if (!ok) { st = __hip_atomic_load(&group_state[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = (uint32_t)(st >> kFsEpochShift) == a.epoch; }
+                }
+                unsigned long long v = ok ? (st & kFsValueMask) : 0ull;
+                uint64_t miss = __ballot(!ok);
+                while (miss) {                                                // not published after all: that group's 64 tiles, summed by the wave
+                    const int L = __ffsll((long long)miss) - 1;
+                    const long long sg = gb - L;
+                    const unsigned long long gsum = wave_sum_u64(fs_tile_sum(a, (sg << 6) + lane));
+                    if (lane == L) v = gsum;
+                    miss &= miss - 1;
                 }
                 front += wave_sum_u64(v);
             }
-            if (lane == 0) {
-                if (tile != 0) __hip_atomic_store(&a.tile_state[tile], fs_pack(a.epoch, 2u, front + S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                front_sh = front;
-            }
+            if (lane == 0) front_sh = front;
         }
         __syncthreads();
         const int64_t e0 = (int64_t)(front_sh + excl_sh[gib]);
@@ -1943,22 +1964,24 @@ hipError_t ugs_launch_build_prow(const UgsPlanDev &plan, int64_t num_vertices, i
     return hipGetLastError();
 }
 
-hipError_t ugs_launch_scan(const uint32_t *counts, int64_t rows, int64_t *edge_ptr, int64_t *block_tmp, hipStream_t s) {
-    if (rows <= 0) { return hipMemsetAsync(edge_ptr, 0, sizeof(int64_t), s); }
+hipError_t ugs_launch_scan(const uint32_t *counts, int64_t rows, int64_t *edge_ptr, int64_t *block_tmp, hipStream_t s, int64_t *h_total,
+                           uint32_t *h_flag, uint32_t epoch) {
+    if (rows <= 0) { return hipMemsetAsync(edge_ptr, 0, sizeof(int64_t), s); }          // (callers do not ask for the signal then)
+    const ScanSignal sg{h_total, h_flag, epoch};
     // one block pays only while it needs a round or two (measured: 65 536 rows in 8 rounds 60 us against 13 us + gaps for the
     // three launches; 8 192 rows in one round instead of four 256-thread rounds: C3 step 80 -> 79 us)
     if (rows <= (int64_t)2 * kScanWide * kScanPer) {
-        hipLaunchKernelGGL(ugs_scan_small, dim3(1), dim3(kScanWide), 0, s, counts, rows, edge_ptr);
+        hipLaunchKernelGGL(ugs_scan_small, dim3(1), dim3(kScanWide), 0, s, counts, rows, edge_ptr, sg);
         return hipGetLastError();
     }
     const int64_t nb = (rows + kScanTile - 1) / kScanTile;
     hipLaunchKernelGGL(ugs_scan_partials, dim3((unsigned)nb), dim3(kScanBlock), 0, s, counts, rows, block_tmp);
     if (nb <= 4096) {
-        hipLaunchKernelGGL(ugs_scan_final_sum, dim3((unsigned)nb), dim3(kScanBlock), 0, s, counts, rows, (const int64_t *)block_tmp, edge_ptr);
+        hipLaunchKernelGGL(ugs_scan_final_sum, dim3((unsigned)nb), dim3(kScanBlock), 0, s, counts, rows, (const int64_t *)block_tmp, edge_ptr, sg);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(ugs_scan_block_sums, dim3(1), dim3(kScanBlock), 0, s, block_tmp, nb);
-    hipLaunchKernelGGL(ugs_scan_final, dim3((unsigned)nb), dim3(kScanBlock), 0, s, counts, rows, (const int64_t *)block_tmp, edge_ptr);
+    hipLaunchKernelGGL(ugs_scan_final, dim3((unsigned)nb), dim3(kScanBlock), 0, s, counts, rows, (const int64_t *)block_tmp, edge_ptr, sg);
     return hipGetLastError();
 }
 

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64, 5) void probe_flush(uint32_t *out, const uint32
     PROBE_PRE
     uint4 en = make_uint4(0, 0, 0, 0); uint32_t ecol = 0;
     if (threadIdx.x < c) { en = pw.EL[threadIdx.x]; ecol = (uint32_t)adjf[en.x].y; }
-    stage_flush(c, g, pw.SV, rsel, en, ecol, stage, reinterpret_cast<uint32_t *>(pw.EL));
+    stage_flush(c, g, pw.SV, rsel, en, ecol, stage);
     out[threadIdx.x] = lds[(threadIdx.x + c) & 63];
 }
 template __global__ void probe_mat<0>(uint32_t *, const uint32_t *, uint32_t, uint32_t);
