@@ -65,7 +65,7 @@ struct UgsWalkArgs {
     int32_t m;               // samples per graph
     int32_t k;
     int32_t mode;            // UGS_MODE_* / UGS_EDGE_* (0 local, 1 flat, 2 global)
-    int32_t pad;
+    int32_t graph_cache;     // 8-lane tier: 1 = every graph is small (<= 256 vertices), the walk blocks keep the graph of their rows in LDS
     int64_t extra_node_off;  // handle API "global": base_offset
     uint64_t seed64;         // (uint64_t)(int64_t)seed
     const uint64_t *seed_ptr;// if not NULL the seed is read from here (captured HIP graphs: the value changes between replays)
@@ -94,6 +94,7 @@ struct UgsWalkArgs {
     // groups_total + atomicAdd(work_next, 1) (NULL: static striding).  A walk's cost varies (degrees, which stages of the order
     // get invalidated), so a static split ends with the unluckiest wave.
     unsigned long long *work_next;
+    uint32_t *wsum;          // 8-lane tier, optional: [ceil(row_count / 8)] sum of the counts of every 8 consecutive rows (for ugs_fill_scan)
     uint2 *stage;            // [row_count, UGS_STAGE_ITEMS]: x = batch column, y = source local index | target local index << 8
     int64_t *ulist;          // rows (relative) with edges that are NOT staged
     uint32_t *ucount;
@@ -117,11 +118,9 @@ struct UgsFillArgs {
     const int64_t *ulist;      // with staging: the rows the row-reading kernel still has to do
     const uint32_t *ucount;
     // scan folded into the fill (small-batch step, ugs_fill_scan): the kernel turns the walk's per-row counts into edge_ptr itself --
-    // tiles of 32 rows, a tile's offset by looking back over the published sums of the tiles in front of it
+    // tiles of 32 rows, a tile's offset from the sums of 8 rows the walk kernel left
     int64_t *edge_ptr_out;              // [row_count + 1], written by the kernel (NULL: edge_ptr above is read)
-    unsigned long long *tile_state;     // [tiles + ceil(tiles / 64)]: epoch << 40 | value -- a tile's sum; behind them the sums of the groups of 64 tiles
-    uint32_t epoch;                     // names the launch: states of earlier launches are stale, no memset between calls
-    uint32_t pad2;
+    const uint32_t *wsum;               // [ceil(row_count / 8)]: UgsWalkArgs::wsum of the walk of the same rows
 };
 
 struct UgsLaunchInfo {

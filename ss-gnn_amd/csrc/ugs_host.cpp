@@ -508,10 +508,9 @@ struct ugs_plan {
     // edges staged by the last walk (UgsWalkArgs::stage) and the call they belong to: a fill of exactly those rows into/from
     // the same nodes buffer expands them; any other fill reads the adjacency rows again
     PoolBuf stage, ulist, work;   // work: 3 x u64 next-item counters (one per walk launch of a call)
-    // scan folded into the fill (ugs_plan_step, ugs_fill_scan): one state word per tile of 32 rows; the states carry the launch's epoch:
-    // no memset between steps
+    // scan folded into the fill (ugs_plan_step, ugs_fill_scan): the walk kernel's sums of 8 consecutive rows
     PoolBuf tiles;
-    uint32_t tile_epoch = 0;
+    int small_graphs = -1;                // 1: every graph has at most 256 vertices (the 8-lane tier's walks keep their graph in LDS); -1: not looked at yet
     // job path: the scan kernel hands the edge total to the host through 16 bytes of pinned memory (total, epoch word) and the host
     // polls the word instead of copying the total back behind a stream wait (wait_signal)
     char *pin_slot = nullptr;
@@ -1836,6 +1835,23 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
         plan->stg_m = m_per_graph; plan->stg_k = k;
     }
     a.work_next = dyn ? static_cast<unsigned long long *>(plan->work.p) + 0 : nullptr;
+    // ugs_plan_step: the fill kernel can turn the counts into edge_ptr itself when the walk leaves the sums of 8 rows beside them --
+    // 8-lane tier, rows taken by index (static split), no walk handed on, no capture in progress, a row count the fill's blocks can
+    // add up in a few dozen loads per thread
+    const bool defer = defer_scan && !total_edges_host && tc.first == UGS_TIER_S && !may_overflow && !dyn && row_count <= 131072 && !capturing(s) &&
+                       std::getenv("UGS_NO_FUSED_SCAN") == nullptr;
+    if (defer) {
+        if (int rc = ensure(plan->tiles, std::max<size_t>((size_t)((row_count + 7) / 8) * sizeof(uint32_t), 4096), plan->device, plan)) return rc;
+        a.wsum = static_cast<uint32_t *>(plan->tiles.p);
+    }
+    if (tc.first == UGS_TIER_S && !dyn) {                     // batches of small graphs: the walk blocks keep the graph of their rows in LDS (ugs_walk_lds<8,64,gc>)
+        if (plan->small_graphs < 0) {
+            int64_t nmax = 0;
+            for (int64_t n : plan->g_n) nmax = std::max(nmax, n);
+            plan->small_graphs = nmax <= 256 ? 1 : 0;
+        }
+        if (plan->small_graphs == 1 && std::getenv("UGS_NO_GRAPH_CACHE") == nullptr) a.graph_cache = 1;
+    }
     HIP_TRY(ev_begin(plan, 0, s));
     HIP_TRY(ugs_launch_walk(a, tc.first, plan->cus, plan->walk_share, s, &plan->last_walk));
     HIP_TRY(ev_end(plan, s));
@@ -1875,7 +1891,6 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
         HIP_TRY(ugs_launch_walk(a, UGS_TIER_G, plan->cus, plan->walk_share, s, nullptr));
         last = 2;
     }
-    const bool defer = defer_scan && !total_edges_host && tc.first == UGS_TIER_S && !capturing(s) && std::getenv("UGS_NO_FUSED_SCAN") == nullptr;
     // the library's own jobs (poll_total): the scan kernel hands the total to the host and the host polls for it -- the caller of the job
     // API gets its outputs from later operations on the same stream, so nothing else needs the stream to be idle here.  Not while rows
     // may have been handed on (the overflow counters are read back with the total) and not under UGS_DEBUG.
@@ -1955,14 +1970,6 @@ int ugs_plan_step(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
     HIP_TRY(hipSetDevice(plan->device));
     std::lock_guard<std::mutex> lk(plan->mu);
     if (int rc = plan_enter(plan, s)) return rc;
-    const int64_t tiles = ugs_fill_scan_tiles(row_count);
-    const size_t need = (size_t)(tiles + (tiles + 63) / 64) * sizeof(unsigned long long);       // a word per tile, a word per group of 64 tiles
-    const bool fresh = !plan->tiles.p || plan->tiles.bytes < need;
-    if (fresh) { if (int rc = ensure(plan->tiles, std::max<size_t>(need, 4096), plan->device, plan)) return rc; }
-    if (fresh || ++plan->tile_epoch >= (1u << 24)) {        // a buffer from the pool holds anything; a wrapped epoch would meet its own old states
-        HIP_TRY(hipMemsetAsync(plan->tiles.p, 0, plan->tiles.bytes, s));
-        plan->tile_epoch = 1;
-    }
     UgsFillArgs a{};
     a.plan = plan->dev;
     a.m = m_per_graph; a.k = k; a.mode = mode;
@@ -1971,8 +1978,7 @@ int ugs_plan_step(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extr
     a.nodes = d_nodes; a.edge_ptr = d_edge_ptr; a.edge_ptr_out = d_edge_ptr;
     a.edge_index = d_edge_index; a.ld = ld; a.edge_src = d_edge_src;
     a.counts = static_cast<const uint32_t *>(plan->counts.p);
-    a.tile_state = static_cast<unsigned long long *>(plan->tiles.p);
-    a.epoch = plan->tile_epoch;
+    a.wsum = static_cast<const uint32_t *>(plan->tiles.p);
     HIP_TRY(ev_begin(plan, 2, s));
     HIP_TRY(ugs_launch_fill_scan(a, plan->cus, s, &plan->last_fill));
     HIP_TRY(ev_end(plan, s));

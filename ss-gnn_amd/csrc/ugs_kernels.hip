@@ -1045,13 +1045,13 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
 
 // row of v through the row pointer (8-lane tier, global-memory tier, plans without padded rows)
 template <int GS, class SP, bool ADD, bool STG>
-__device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, const UgsPlanDev &P, uint32_t v,
+__device__ __forceinline__ bool scan_row(const Work<SP> &ws, const Grp<GS> &g, const int2 *adj, uint32_t v,
                                          uint32_t root_vi, uint32_t size, uint32_t &c, uint32_t &hcount,
                                          uint32_t &ecount, uint32_t r0, uint32_t r1, StageCtx &sc) {
     for (uint32_t base = r0; base < r1; base += GS) {
         const uint32_t p = base + (uint32_t)g.lane;
         int2 e = UGS_NO_ENTRY;
-        if (p < r1) e = P.adj[p];
+        if (p < r1) e = adj[p];
         if (!scan_chunk<GS, SP, ADD, STG>(ws, g, v, root_vi, size, c, hcount, ecount, sc, e, p)) return false;
     }
     return true;
@@ -1157,10 +1157,18 @@ __device__ __forceinline__ void stage_flush(uint32_t ne, const Grp<64> &g, const
     if (mirror) out[rb] = make_uint2(ecol, ei | (es << 8));
 }
 
+// Graph cache of the 8-lane tier (ugs_walk_lds<..., GC = true>): the row pointer, adjacency and root records of ONE small graph
+// copied into LDS by the block; the pointers are pre-offset so that the plan's own indices address them (rowptr[gd.rbase + v],
+// adj[p] with absolute p, roots[gd.vbase + j]).  A group whose row belongs to the cached graph reads LDS, any other the plan.
+struct GcView { const int64_t *rowptr; const int2 *adj; const UgsRootRec *roots; int64_t gi; };
+constexpr int kGcMaxN = 256, kGcMaxE = 1024;
+
 // One walk.  Returns false on workspace overflow (the row is then redone by the next tier).
-template <int GS, class SP, int MAXPER, bool PAD>
+template <int GS, class SP, int MAXPER, bool PAD, bool GC = false>
 __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, const UgsWalkArgs &a, int64_t row_rel,
-                                        uint32_t *SV /* [UGS_KMAX] group-private */, uint4 *EL /* [UGS_STAGE_ENTRIES] or null */) {
+                                        uint32_t *SV /* [UGS_KMAX] group-private */, uint4 *EL /* [UGS_STAGE_ENTRIES] or null */,
+                                        uint32_t *nedges_out = nullptr /* the row's edge-entry count (0 if the walk is handed on) */,
+                                        const GcView *gc = nullptr) {
     static_assert(!PAD || GS == 64, "padded rows are read by a whole wave");
     const Grp<GS> &g = g_;
     constexpr bool STG = GS == 64 && sizeof(typename SP::TW) == 4;             // one walk per wave, LDS workspace
@@ -1174,6 +1182,12 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
     const UgsGraphDesc gd = P.graphs[gi];
     const int k = a.k;
     int64_t *out = a.nodes + row_rel * k;
+    // where this walk reads its graph: the plan's arrays, or the block's LDS copy of the graph (GC)
+    const int64_t *g_rowptr = P.rowptr;
+    const int2 *g_adj = P.adj;
+    const UgsRootRec *g_roots = P.roots;
+    if constexpr (GC) { if (gc->gi == gi) { g_rowptr = gc->rowptr; g_adj = gc->adj; g_roots = gc->roots; } }
+    if (nedges_out) *nedges_out = 0u;
     if (gd.level < 0) {   // degenerate graph: m rows of -1, no edges (reference src/ugs_sampler_batch_extension.cpp:132-143)
         for (int j = g.lane; j < k; j += GS) out[j] = -1;
         if (g.lane == 0) a.counts[row_rel] = 0;
@@ -1193,7 +1207,7 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
     if (gd.level == 0) {      // alias draw: two numbers (reference include/sampler.hpp:72-77)
         j = mod64_root(rng.next(), (uint32_t)gd.n);
         u = (double)rng.next() * 0x1p-64;           // == / (double)UINT64_MAX (which is 2^64): exact scaling
-        rr = P.roots[gd.vbase + j];
+        rr = g_roots[gd.vbase + j];
     } else {                  // relaxed: uniform over the viable list, one number (reference src/sampler.cpp:169-172)
         const uint32_t idx = mod64_root(rng.next(), (uint32_t)gd.n_viable);
         vr = P.viable[gd.viable_base + idx];
@@ -1216,7 +1230,7 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
     int2 e0 = make_int2(0, 0);
     uint32_t v = root_v;                                                      // the vertex whose row is scanned next (local index size-1)
     if constexpr (PAD) e0 = load_prow(P, gd.vbase + v, g.lane);
-    else { r0 = g.uni((uint32_t)P.rowptr[gd.rbase + v]); r1 = g.uni((uint32_t)P.rowptr[gd.rbase + v + 1]); }
+    else { r0 = g.uni((uint32_t)g_rowptr[gd.rbase + v]); r1 = g.uni((uint32_t)g_rowptr[gd.rbase + v + 1]); }
     SP::sync();
     if (g.lane == 0) { ws.HK[hash_slot(root_v, ws.hmask)] = root_v | kInS; SV[0] = root_v; }
     SP::sync();
@@ -1251,10 +1265,10 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
         bool ok;
         if (step < k - 1) {                                                   // the last vertex adds no candidates
             if constexpr (PAD) ok = scan_prow<SP, true, STG>(ws, g, P, v, root_vi, size, c, hcount, ecount, e0, gd.vbase + v, sc);
-            else ok = scan_row<GS, SP, true, STG>(ws, g, P, v, root_vi, size, c, hcount, ecount, r0, r1, sc);
+            else ok = scan_row<GS, SP, true, STG>(ws, g, g_adj, v, root_vi, size, c, hcount, ecount, r0, r1, sc);
         } else {
             if constexpr (PAD) ok = scan_prow<SP, false, STG>(ws, g, P, v, root_vi, size, c, hcount, ecount, e0, gd.vbase + v, sc);
-            else ok = scan_row<GS, SP, false, STG>(ws, g, P, v, root_vi, size, c, hcount, ecount, r0, r1, sc);
+            else ok = scan_row<GS, SP, false, STG>(ws, g, g_adj, v, root_vi, size, c, hcount, ecount, r0, r1, sc);
         }
         STAMP_END(1);
         if (!ok) return false;
@@ -1266,8 +1280,8 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
         if constexpr (PAD) {
             e0 = load_prow(P, gd.vbase + w, g.lane);                  // the row itself: issued now, consumed after the candidate list has been updated
         } else {
-            r0 = (uint32_t)P.rowptr[gd.rbase + w];
-            r1 = (uint32_t)P.rowptr[gd.rbase + w + 1];
+            r0 = (uint32_t)g_rowptr[gd.rbase + w];
+            r1 = (uint32_t)g_rowptr[gd.rbase + w + 1];
             r0 = g.uni(r0); r1 = g.uni(r1);
         }
         STAMP_END(2);
@@ -1354,6 +1368,7 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
     for (int j = g.lane; j < k; j += GS) out[j] = (j < (int)size) ? (int64_t)SV[j] + off : (int64_t)-1;
     // one word per row: the edge-entry count and, in its top bit, whether the row's items are staged (one store instead of two)
     if (g.lane == 0) a.counts[row_rel] = nedges | (flush ? UGS_COUNT_STAGED : 0u);
+    if (nedges_out) *nedges_out = nedges;
     if (a.stage) {                                                               // staging is on for this call
         if constexpr (STG) { if (flush) stage_flush(sc.ne, g, SV, (uint32_t)k, en, ecol, a.stage + row_rel * UGS_STAGE_ITEMS); }
         if (g.lane == 0 && !flush && nedges != 0u) a.ulist[atomicAdd(a.ucount, 1u)] = row_rel;
@@ -1381,11 +1396,16 @@ template <int CAP> struct TierCfg {
 // admits 18 one-wave blocks per CU (5,5,4,4 per SIMD).  With a STATIC split of the rows 18 blocks/CU was slower than 16
 // (10.63 vs 10.43 ms: a launch ended with the waves of the fuller SIMDs); with the shared work counter the extra waves are
 // pure throughput: 8.81 -> 8.51 ms.  Spilling further to reach more waves costs more than it brings (30 % in an early build).
-template <int GS, int CAP, int BLOCK, bool PAD>
+template <int GS, int CAP, int BLOCK, bool PAD, bool GC = false>
 __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP == 704 ? 3 : (CAP <= 64 || CAP == 1024 || CAP == 1408 ? 2 : 1))) void ugs_walk_lds(UgsWalkArgs a) {
     using Cfg = TierCfg<CAP>;
     constexpr int GROUPS = BLOCK / GS;
+    static_assert(!GC || GS == 8, "the graph cache belongs to the 8-lane tier (batches of small graphs)");
     __shared__ __attribute__((aligned(16))) uint32_t lds[GROUPS * Cfg::WORDS];
+    // GC: one small graph in LDS (16.4 KB beside the 51.7 KB of the 32 walks: two blocks per CU instead of three)
+    __shared__ __attribute__((aligned(16))) int64_t c_rp[GC ? kGcMaxN + 1 : 1];
+    __shared__ __attribute__((aligned(16))) int2 c_adj[GC ? kGcMaxE : 1];
+    __shared__ __attribute__((aligned(16))) unsigned long long c_roots[GC ? 3 * kGcMaxN : 1];      // UgsRootRec = 3 x 8 bytes
     Grp<GS> g;
     g.init();
     if constexpr (GS == 64) g.chain = chain_lane_const<Cfg::NSTAGE>(g.lane);
@@ -1441,6 +1461,60 @@ __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP == 704 ?
             end = it + chunk;
         }
         return;
+    }
+    if constexpr (GS == 8) {
+        if (a.wsum || GC) {
+            // The block's 32 groups take 32 consecutive rows per trip and stay together (every thread makes the same trips):
+            //  * small-batch step (ugs_plan_step, a.wsum): beside the per-row counts the walk leaves the SUM of every 8 consecutive
+            //    rows -- the 8 groups of a wave come back from their walks together -- so that the fill kernel can add up what lies in
+            //    front of a tile from plain, cacheable words written by the kernel BEFORE it (no communication between the fill's
+            //    blocks: that cost 15 us on the QM9-shaped batch, see ugs_fill_scan);
+            //  * graph cache (GC): a PyG batch gives a graph m consecutive rows, so the 32 rows of a trip belong to one graph (two at
+            //    a boundary): the block copies that graph's row pointer, adjacency and root records into LDS -- a few KB, coalesced
+            //    -- and the walks read every row from there instead of one dependent L2 round trip per row pointer and per row.
+            // Rows are taken by index (no list of handed-on rows: the host picks this form only for first-tier launches).
+            GcView gc{a.plan.rowptr, a.plan.adj, a.plan.roots, -1};
+            int64_t cached = -2;
+            for (int64_t it0 = (int64_t)blockIdx.x * GROUPS; it0 < total; it0 += ngroups) {
+                const int64_t it = it0 + gib;
+                if constexpr (GC) {
+                    const int64_t row0 = a.row_begin + it0;
+                    const int64_t gi0 = a.plan.num_graphs == 1 ? 0 : row0 / a.m;
+                    if (gi0 != cached) {                                                 // block-uniform
+                        __syncthreads();                                                  // nobody reads the old copy any more
+                        const UgsGraphDesc gd0 = a.plan.graphs[gi0];
+                        cached = gi0;
+                        gc.gi = -1;
+                        if (gd0.level >= 0 && gd0.n <= kGcMaxN) {
+                            const int64_t a0 = a.plan.rowptr[gd0.rbase], nnz = a.plan.rowptr[gd0.rbase + gd0.n] - a0;
+                            if (nnz <= kGcMaxE) {
+                                for (int x = (int)threadIdx.x; x <= gd0.n; x += BLOCK) c_rp[x] = a.plan.rowptr[gd0.rbase + x];
+                                for (int e = (int)threadIdx.x; e < (int)nnz; e += BLOCK) c_adj[e] = a.plan.adj[a0 + e];
+                                gc.rowptr = reinterpret_cast<const int64_t *>(reinterpret_cast<uintptr_t>(c_rp) - (uintptr_t)gd0.rbase * sizeof(int64_t));
+                                gc.adj = reinterpret_cast<const int2 *>(reinterpret_cast<uintptr_t>(c_adj) - (uintptr_t)a0 * sizeof(int2));
+                                gc.roots = a.plan.roots;
+                                if (gd0.level == 0) {                                     // the alias rows (relaxed levels keep their viable list in HBM)
+                                    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.plan.roots + gd0.vbase);
+                                    for (int x = (int)threadIdx.x; x < 3 * gd0.n; x += BLOCK) c_roots[x] = src[x];
+                                    gc.roots = reinterpret_cast<const UgsRootRec *>(reinterpret_cast<uintptr_t>(c_roots) - (uintptr_t)gd0.vbase * sizeof(UgsRootRec));
+                                }
+                                gc.gi = gi0;
+                            }
+                        }
+                        __syncthreads();
+                    }
+                }
+                uint32_t ne = 0u;
+                if (it < total) (void)do_walk<GS, LdsSpace, (CAP + GS - 1) / GS, PAD, GC>(ws, g, a, it, SV, EL, &ne, &gc);
+                if (a.wsum) {
+                    uint32_t sum = g.lane == 0 ? ne : 0u;
+                    sum += __shfl_xor(sum, 8, 64); sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+                    const int64_t w0 = it0 + (int64_t)((threadIdx.x >> 6) * 8);      // first row of this wave
+                    if ((threadIdx.x & 63) == 0 && w0 < total) a.wsum[w0 >> 3] = sum;
+                }
+            }
+            return;
+        }
     }
     for (int64_t it = (int64_t)blockIdx.x * GROUPS + gib; it < total; it += ngroups) {
         const int64_t row_rel = a.in_list ? a.in_list[it] : it;
@@ -1761,48 +1835,23 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
 }
 
 // The small-batch step in two launches instead of three: the fill kernel of the 8-lane tier with the exclusive scan of the walk's
-// per-row counts folded in (reference semantics of edge_ptr: src/sampler.cpp:249-287).  A block takes tiles of 32 consecutive rows and
-// publishes its tile's sum; the last tile of every GROUP of 64 tiles adds the group's sums up and publishes that too.  A tile's offset
-// is then two short reads: the sums of the groups in front of its own (one word per 2048 rows) and the sums of the tiles in front of
-// it inside its group (at most 63 words) -- no chain from tile to tile, whatever the number of tiles.  (Version one handed tiles out
-// by tickets from one counter: 2048 atomics on one address, 61 us for the QM9-shaped batch.  Version two looked back tile by tile
-// to the nearest published prefix: with every tile of a small batch starting at once nobody has a prefix yet, and the last tile read
-// all 2047 sums in front of it, 32-40 us.)  NOTHING DEPENDS ON ANOTHER BLOCK BEING SCHEDULED: a tile sum that is not published yet
-// is recomputed from the counts themselves (they are final: the walk kernels are over); a group sum is waited for a bounded number
-// of polls and then recomputed from its tiles.  One 64-bit word per sum carries the launch's epoch beside the value: stale epochs
-// read as "not published", so a step needs no memset.
-constexpr int kFsEpochShift = 40;
-constexpr unsigned long long kFsValueMask = (1ull << kFsEpochShift) - 1ull;
-__device__ __forceinline__ unsigned long long fs_pack(uint32_t epoch, unsigned long long v) { return ((unsigned long long)epoch << kFsEpochShift) | (v & kFsValueMask); }
-__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long x) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) x += (unsigned long long)__shfl_xor((long long)x, d, 64);
-    return x;
-}
-// sum of tile `idx` (a full tile: it has a successor) for a lane: its published word, or the 32 counts (128-byte aligned: pool buffers)
-__device__ __forceinline__ unsigned long long fs_tile_sum(const UgsFillArgs &a, long long idx) {
-    const unsigned long long st = __hip_atomic_load(&a.tile_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((uint32_t)(st >> kFsEpochShift) == a.epoch) return st & kFsValueMask;
-    const uint4 *q = reinterpret_cast<const uint4 *>(a.counts + idx * 32);
-    unsigned long long v = 0ull;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const uint4 w = q[t];
-        v += (unsigned long long)(w.x & ~UGS_COUNT_STAGED) + (w.y & ~UGS_COUNT_STAGED) + (w.z & ~UGS_COUNT_STAGED) + (w.w & ~UGS_COUNT_STAGED);
-    }
-    return v;
-}
-
+// per-row counts folded in (reference semantics of edge_ptr: src/sampler.cpp:249-287).  A block takes tiles of 32 consecutive rows; what
+// lies in front of a tile it adds up itself from the sums of 8 rows the WALK kernel left (UgsWalkArgs::wsum: 4 words per tile, at most
+// 64 loads per thread for the 131 072 rows this form serves) -- plain cacheable reads of words written by the previous kernel.
+// No block talks to another.  Three versions that did were measured first (same outputs, tests/test_gpu_parity.py): tiles handed out by
+// tickets and a look-back chain (2048 atomics on one address: 61 us for the fill of the QM9-shaped batch), look-back without tickets
+// (every tile of a small batch starts at once, nobody has a prefix yet: 32-40 us), tile sums + sums of groups of 64 tiles (33 us:
+// the agent-scope loads and stores that carry the sums between blocks on different XCDs cost 15 us whatever is waited for or not).
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void ugs_fill_scan(UgsFillArgs a) {
     constexpr int GS = 8, GROUPS = BLOCK / GS;
-    static_assert(GROUPS == 32, "a tile is 32 rows: eight 16-byte loads of counts");
+    static_assert(GROUPS == 32, "a tile is 32 rows = four of the walk's 8-row sums");
     __shared__ uint32_t sv_all[GROUPS * UGS_KMAX];
     __shared__ uint32_t ps_all[GROUPS * (UGS_KMAX + 1)];
     __shared__ int64_t r0_all[GROUPS * UGS_KMAX];
     __shared__ uint32_t cnt_sh[GROUPS];
     __shared__ unsigned long long excl_sh[GROUPS];
-    __shared__ unsigned long long front_sh;
+    __shared__ unsigned long long part_sh[BLOCK / 64];
     Grp<GS> g;
     g.init();
     const int gib = (int)threadIdx.x / GS;
@@ -1812,56 +1861,31 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill_scan(UgsFillArgs a) {
     const UgsPlanDev &P = a.plan;
     const int k = a.k;
     const long long ntiles = (long long)((a.row_count + GROUPS - 1) / GROUPS);
-    unsigned long long *group_state = a.tile_state + ntiles;             // one word per group of 64 tiles, behind the tiles' words
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row_rel = (int64_t)tile * GROUPS + gib;
         const bool in = row_rel < a.row_count;
         const uint32_t c = in ? (a.counts[row_rel] & ~UGS_COUNT_STAGED) : 0u;
         if (g.lane == 0) cnt_sh[gib] = c;
+        // everything in front of the tile: the block's threads share the walk's 8-row sums
+        unsigned long long before = 0ull;
+        for (long long i = threadIdx.x; i < 4 * tile; i += BLOCK) before += a.wsum[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) before += (unsigned long long)__shfl_xor((long long)before, d, 64);
+        if ((threadIdx.x & 63) == 0) part_sh[threadIdx.x >> 6] = before;
         __syncthreads();
-        if (threadIdx.x < 64) {
+        if (threadIdx.x < 64) {                                       // the tile's own 32 counts
             const int lane = (int)threadIdx.x;
             const uint32_t x = lane < GROUPS ? cnt_sh[lane] : 0u;
             uint32_t incl = x;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
-            const unsigned long long S = (unsigned long long)__shfl(incl, 63, 64);
             if (lane < GROUPS) excl_sh[lane] = (unsigned long long)(incl - x);
-            if (lane == 0) __hip_atomic_store(&a.tile_state[tile], fs_pack(a.epoch, S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const long long grp = tile >> 6, g0 = grp << 6;
-            // the tiles in front of this one inside its group
-            const long long idx = tile - 1 - lane;
-            unsigned long long front = wave_sum_u64(idx >= g0 ? fs_tile_sum(a, idx) : 0ull);
-            if ((tile & 63) == 63 && lane == 0)                              // the group is complete with this tile: its sum for the tiles behind it
-                __hip_atomic_store(&group_state[grp], fs_pack(a.epoch, front + S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // the groups in front of this tile's group
-            for (long long gb = grp - 1; gb >= 0; gb -= 64) {
-                const long long sidx = gb - lane;
-                unsigned long long st = fs_pack(a.epoch, 0ull);
-                bool ok = true;
-                if (sidx >= 0) {
-                    st = __hip_atomic_load(&group_state[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = (uint32_t)(st >> kFsEpochShift) == a.epoch;
-                }
-                for (int spin = 0; spin < 64 && __ballot(!ok); ++spin) {      // the group's last tile publishes within a microsecond or two of the launch
-                    __builtin_amdgcn_s_sleep(8);
-                    if (!ok) { st = __hip_atomic_load(&group_state[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = (uint32_t)(st >> kFsEpochShift) == a.epoch; }
-                }
-                unsigned long long v = ok ? (st & kFsValueMask) : 0ull;
-                uint64_t miss = __ballot(!ok);
-                while (miss) {                                                // not published after all: that group's 64 tiles, summed by the wave
-                    const int L = __ffsll((long long)miss) - 1;
-                    const long long sg = gb - L;
-                    const unsigned long long gsum = wave_sum_u64(fs_tile_sum(a, (sg << 6) + lane));
-                    if (lane == L) v = gsum;
-                    miss &= miss - 1;
-                }
-                front += wave_sum_u64(v);
-            }
-            if (lane == 0) front_sh = front;
         }
         __syncthreads();
-        const int64_t e0 = (int64_t)(front_sh + excl_sh[gib]);
+        unsigned long long front = 0ull;
+#pragma unroll
+        for (int wv = 0; wv < BLOCK / 64; ++wv) front += part_sh[wv];
+        const int64_t e0 = (int64_t)(front + excl_sh[gib]);
         if (in && g.lane == 0) {
             a.edge_ptr_out[row_rel] = e0;
             if (row_rel == a.row_count - 1) a.edge_ptr_out[a.row_count] = e0 + (int64_t)c;
@@ -1917,6 +1941,14 @@ static hipError_t launch_lds(const UgsWalkArgs &a, int cus, int blocks_per_cu, h
     const int64_t cap = (int64_t)cus * blocks_per_cu;
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
+    if constexpr (GS == 8) {
+        if (a.graph_cache == 1 && !a.in_list && !a.work_next) {            // batches of small graphs: the block keeps the graph of its rows in LDS
+            hipLaunchKernelGGL((ugs_walk_lds<GS, CAP, BLOCK, false, true>), dim3((unsigned)grid), dim3(BLOCK), 0, s, a);
+            if (info) { info->name = "ugs_walk_lds<8,64,gc>"; info->grid = (int)grid; info->block = BLOCK;
+                        info->lds_bytes = GROUPS * TierCfg<CAP>::WORDS * 4 + (kGcMaxN + 1) * 8 + kGcMaxE * 8 + kGcMaxN * 24; }
+            return hipGetLastError();
+        }
+    }
     if (kCanPad && a.plan.prow) hipLaunchKernelGGL((ugs_walk_lds<GS, CAP, BLOCK, kCanPad>), dim3((unsigned)grid), dim3(BLOCK), 0, s, a);
     else hipLaunchKernelGGL((ugs_walk_lds<GS, CAP, BLOCK, false>), dim3((unsigned)grid), dim3(BLOCK), 0, s, a);
     if (info) { info->name = name; info->grid = (int)grid; info->block = BLOCK; info->lds_bytes = GROUPS * TierCfg<CAP>::WORDS * 4; }
@@ -1935,7 +1967,7 @@ hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, int share_pe
     // collation, RCCL) find registers, LDS and wave slots on every CU while a walk is running (a full grid holds them to its end)
     auto part = [&](int blocks) { const int b = (int)((long long)blocks * (share_percent <= 0 || share_percent > 100 ? 100 : share_percent) / 100); return b < 1 ? 1 : b; };
     switch (tier) {
-    case UGS_TIER_S: return launch_lds<8, 64, 256>(a, cus, part(UGS_BLOCKS_S), s, info, "ugs_walk_lds<8,64>");
+    case UGS_TIER_S: return launch_lds<8, 64, 256>(a, cus, part(a.graph_cache == 1 && !a.in_list && !a.work_next ? 2 : UGS_BLOCKS_S), s, info, "ugs_walk_lds<8,64>");
     // one walk per wave: two walks per wave (GS 32) measured 26.4 ms vs 18.7 ms per 1M walks on C5 (two chunks per row)
     // resident one-wave blocks per CU: LDS is granted in 1280-byte granules (128 per CU) -- 7648 B = 6 granules -> 21 blocks, of
     // which the register budget (96 VGPRs: 5 waves per SIMD) admits 20; 19.5 KB = 16 granules -> 8; 38.9 KB = 31 granules -> 4
