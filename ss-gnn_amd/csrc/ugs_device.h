@@ -65,7 +65,7 @@ struct UgsWalkArgs {
     int32_t m;               // samples per graph
     int32_t k;
     int32_t mode;            // UGS_MODE_* / UGS_EDGE_* (0 local, 1 flat, 2 global)
-    int32_t graph_cache;     // 8-lane tier: 1 = every graph is small (<= 256 vertices), the walk blocks keep the graph of their rows in LDS
+    int32_t pad;
     int64_t extra_node_off;  // handle API "global": base_offset
     uint64_t seed64;         // (uint64_t)(int64_t)seed
     const uint64_t *seed_ptr;// if not NULL the seed is read from here (captured HIP graphs: the value changes between replays)

@@ -510,7 +510,6 @@ struct ugs_plan {
     PoolBuf stage, ulist, work;   // work: 3 x u64 next-item counters (one per walk launch of a call)
     // scan folded into the fill (ugs_plan_step, ugs_fill_scan): the walk kernel's sums of 8 consecutive rows
     PoolBuf tiles;
-    int small_graphs = -1;                // 1: every graph has at most 256 vertices (the 8-lane tier's walks keep their graph in LDS); -1: not looked at yet
     // job path: the scan kernel hands the edge total to the host through 16 bytes of pinned memory (total, epoch word) and the host
     // polls the word instead of copying the total back behind a stream wait (wait_signal)
     char *pin_slot = nullptr;
@@ -1762,6 +1761,7 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
                           int64_t row_begin, int64_t row_count, void *stream, int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *total_edges_host,
                           bool *defer_scan = nullptr, bool poll_total = false);
 
+
 int ugs_plan_walk(ugs_plan *plan, int m_per_graph, int k, int mode, int64_t extra_node_offset, int seed, int64_t row_begin,
                   int64_t row_count, void *stream, int64_t *d_nodes, int64_t *d_edge_ptr, int64_t *total_edges_host) {
     return plan_walk_impl(plan, m_per_graph, k, mode, extra_node_offset, seed, nullptr, row_begin, row_count, stream, d_nodes, d_edge_ptr, total_edges_host);
@@ -1843,14 +1843,6 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
     if (defer) {
         if (int rc = ensure(plan->tiles, std::max<size_t>((size_t)((row_count + 7) / 8) * sizeof(uint32_t), 4096), plan->device, plan)) return rc;
         a.wsum = static_cast<uint32_t *>(plan->tiles.p);
-    }
-    if (tc.first == UGS_TIER_S && !dyn) {                     // batches of small graphs: the walk blocks keep the graph of their rows in LDS (ugs_walk_lds<8,64,gc>)
-        if (plan->small_graphs < 0) {
-            int64_t nmax = 0;
-            for (int64_t n : plan->g_n) nmax = std::max(nmax, n);
-            plan->small_graphs = nmax <= 256 ? 1 : 0;
-        }
-        if (plan->small_graphs == 1 && std::getenv("UGS_NO_GRAPH_CACHE") == nullptr) a.graph_cache = 1;
     }
     HIP_TRY(ev_begin(plan, 0, s));
     HIP_TRY(ugs_launch_walk(a, tc.first, plan->cus, plan->walk_share, s, &plan->last_walk));

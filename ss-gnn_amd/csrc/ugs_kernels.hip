@@ -1157,18 +1157,16 @@ __device__ __forceinline__ void stage_flush(uint32_t ne, const Grp<64> &g, const
     if (mirror) out[rb] = make_uint2(ecol, ei | (es << 8));
 }
 
-// Graph cache of the 8-lane tier (ugs_walk_lds<..., GC = true>): the row pointer, adjacency and root records of ONE small graph
-// copied into LDS by the block; the pointers are pre-offset so that the plan's own indices address them (rowptr[gd.rbase + v],
-// adj[p] with absolute p, roots[gd.vbase + j]).  A group whose row belongs to the cached graph reads LDS, any other the plan.
-struct GcView { const int64_t *rowptr; const int2 *adj; const UgsRootRec *roots; int64_t gi; };
-constexpr int kGcMaxN = 256, kGcMaxE = 1024;
-
 // One walk.  Returns false on workspace overflow (the row is then redone by the next tier).
-template <int GS, class SP, int MAXPER, bool PAD, bool GC = false>
+// (Round 4 measured a block-wide LDS copy of the walks' graph for the 8-lane tier -- row pointer, adjacency and root records of the
+// graph that owns the block's 32 consecutive rows: PROTEINS-shaped walk 27.8 against 27.0 us, QM9-shaped 59 against 45 us (two blocks
+// per CU instead of three).  An 8-lane walk is a chain of LDS round trips of its own order stages; the two L2 round trips per step it
+// saved do not show.  The same copy for the fill kernels (row pointer and (neighbour, column) entries): 12.4 against 12.4 us and 25.5
+// against 25.0 us.  Neither kept.)
+template <int GS, class SP, int MAXPER, bool PAD>
 __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, const UgsWalkArgs &a, int64_t row_rel,
                                         uint32_t *SV /* [UGS_KMAX] group-private */, uint4 *EL /* [UGS_STAGE_ENTRIES] or null */,
-                                        uint32_t *nedges_out = nullptr /* the row's edge-entry count (0 if the walk is handed on) */,
-                                        const GcView *gc = nullptr) {
+                                        uint32_t *nedges_out = nullptr /* the row's edge-entry count (0 if the walk is handed on) */) {
     static_assert(!PAD || GS == 64, "padded rows are read by a whole wave");
     const Grp<GS> &g = g_;
     constexpr bool STG = GS == 64 && sizeof(typename SP::TW) == 4;             // one walk per wave, LDS workspace
@@ -1182,11 +1180,6 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
     const UgsGraphDesc gd = P.graphs[gi];
     const int k = a.k;
     int64_t *out = a.nodes + row_rel * k;
-    // where this walk reads its graph: the plan's arrays, or the block's LDS copy of the graph (GC)
-    const int64_t *g_rowptr = P.rowptr;
-    const int2 *g_adj = P.adj;
-    const UgsRootRec *g_roots = P.roots;
-    if constexpr (GC) { if (gc->gi == gi) { g_rowptr = gc->rowptr; g_adj = gc->adj; g_roots = gc->roots; } }
     if (nedges_out) *nedges_out = 0u;
     if (gd.level < 0) {   // degenerate graph: m rows of -1, no edges (reference src/ugs_sampler_batch_extension.cpp:132-143)
         for (int j = g.lane; j < k; j += GS) out[j] = -1;
@@ -1207,7 +1200,7 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
     if (gd.level == 0) {      // alias draw: two numbers (reference include/sampler.hpp:72-77)
         j = mod64_root(rng.next(), (uint32_t)gd.n);
         u = (double)rng.next() * 0x1p-64;           // == / (double)UINT64_MAX (which is 2^64): exact scaling
-        rr = g_roots[gd.vbase + j];
+        rr = P.roots[gd.vbase + j];
     } else {                  // relaxed: uniform over the viable list, one number (reference src/sampler.cpp:169-172)
         const uint32_t idx = mod64_root(rng.next(), (uint32_t)gd.n_viable);
         vr = P.viable[gd.viable_base + idx];
@@ -1230,7 +1223,7 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
     int2 e0 = make_int2(0, 0);
     uint32_t v = root_v;                                                      // the vertex whose row is scanned next (local index size-1)
     if constexpr (PAD) e0 = load_prow(P, gd.vbase + v, g.lane);
-    else { r0 = g.uni((uint32_t)g_rowptr[gd.rbase + v]); r1 = g.uni((uint32_t)g_rowptr[gd.rbase + v + 1]); }
+    else { r0 = g.uni((uint32_t)P.rowptr[gd.rbase + v]); r1 = g.uni((uint32_t)P.rowptr[gd.rbase + v + 1]); }
     SP::sync();
     if (g.lane == 0) { ws.HK[hash_slot(root_v, ws.hmask)] = root_v | kInS; SV[0] = root_v; }
     SP::sync();
@@ -1265,10 +1258,10 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
         bool ok;
         if (step < k - 1) {                                                   // the last vertex adds no candidates
             if constexpr (PAD) ok = scan_prow<SP, true, STG>(ws, g, P, v, root_vi, size, c, hcount, ecount, e0, gd.vbase + v, sc);
-            else ok = scan_row<GS, SP, true, STG>(ws, g, g_adj, v, root_vi, size, c, hcount, ecount, r0, r1, sc);
+            else ok = scan_row<GS, SP, true, STG>(ws, g, P.adj, v, root_vi, size, c, hcount, ecount, r0, r1, sc);
         } else {
             if constexpr (PAD) ok = scan_prow<SP, false, STG>(ws, g, P, v, root_vi, size, c, hcount, ecount, e0, gd.vbase + v, sc);
-            else ok = scan_row<GS, SP, false, STG>(ws, g, g_adj, v, root_vi, size, c, hcount, ecount, r0, r1, sc);
+            else ok = scan_row<GS, SP, false, STG>(ws, g, P.adj, v, root_vi, size, c, hcount, ecount, r0, r1, sc);
         }
         STAMP_END(1);
         if (!ok) return false;
@@ -1280,8 +1273,8 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
         if constexpr (PAD) {
             e0 = load_prow(P, gd.vbase + w, g.lane);                  // the row itself: issued now, consumed after the candidate list has been updated
         } else {
-            r0 = (uint32_t)g_rowptr[gd.rbase + w];
-            r1 = (uint32_t)g_rowptr[gd.rbase + w + 1];
+            r0 = (uint32_t)P.rowptr[gd.rbase + w];
+            r1 = (uint32_t)P.rowptr[gd.rbase + w + 1];
             r0 = g.uni(r0); r1 = g.uni(r1);
         }
         STAMP_END(2);
@@ -1396,16 +1389,11 @@ template <int CAP> struct TierCfg {
 // admits 18 one-wave blocks per CU (5,5,4,4 per SIMD).  With a STATIC split of the rows 18 blocks/CU was slower than 16
 // (10.63 vs 10.43 ms: a launch ended with the waves of the fuller SIMDs); with the shared work counter the extra waves are
 // pure throughput: 8.81 -> 8.51 ms.  Spilling further to reach more waves costs more than it brings (30 % in an early build).
-template <int GS, int CAP, int BLOCK, bool PAD, bool GC = false>
+template <int GS, int CAP, int BLOCK, bool PAD>
 __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP == 704 ? 3 : (CAP <= 64 || CAP == 1024 || CAP == 1408 ? 2 : 1))) void ugs_walk_lds(UgsWalkArgs a) {
     using Cfg = TierCfg<CAP>;
     constexpr int GROUPS = BLOCK / GS;
-    static_assert(!GC || GS == 8, "the graph cache belongs to the 8-lane tier (batches of small graphs)");
     __shared__ __attribute__((aligned(16))) uint32_t lds[GROUPS * Cfg::WORDS];
-    // GC: one small graph in LDS (16.4 KB beside the 51.7 KB of the 32 walks: two blocks per CU instead of three)
-    __shared__ __attribute__((aligned(16))) int64_t c_rp[GC ? kGcMaxN + 1 : 1];
-    __shared__ __attribute__((aligned(16))) int2 c_adj[GC ? kGcMaxE : 1];
-    __shared__ __attribute__((aligned(16))) unsigned long long c_roots[GC ? 3 * kGcMaxN : 1];      // UgsRootRec = 3 x 8 bytes
     Grp<GS> g;
     g.init();
     if constexpr (GS == 64) g.chain = chain_lane_const<Cfg::NSTAGE>(g.lane);
@@ -1463,55 +1451,20 @@ __global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP == 704 ?
         return;
     }
     if constexpr (GS == 8) {
-        if (a.wsum || GC) {
-            // The block's 32 groups take 32 consecutive rows per trip and stay together (every thread makes the same trips):
-            //  * small-batch step (ugs_plan_step, a.wsum): beside the per-row counts the walk leaves the SUM of every 8 consecutive
-            //    rows -- the 8 groups of a wave come back from their walks together -- so that the fill kernel can add up what lies in
-            //    front of a tile from plain, cacheable words written by the kernel BEFORE it (no communication between the fill's
-            //    blocks: that cost 15 us on the QM9-shaped batch, see ugs_fill_scan);
-            //  * graph cache (GC): a PyG batch gives a graph m consecutive rows, so the 32 rows of a trip belong to one graph (two at
-            //    a boundary): the block copies that graph's row pointer, adjacency and root records into LDS -- a few KB, coalesced
-            //    -- and the walks read every row from there instead of one dependent L2 round trip per row pointer and per row.
-            // Rows are taken by index (no list of handed-on rows: the host picks this form only for first-tier launches).
-            GcView gc{a.plan.rowptr, a.plan.adj, a.plan.roots, -1};
-            int64_t cached = -2;
+        if (a.wsum) {
+            // Small-batch step (ugs_plan_step): beside the per-row counts the walk leaves the SUM of every 8 consecutive rows -- the
+            // 8 groups of a wave hold 8 consecutive rows and come back from their walks together -- so that the fill kernel can add
+            // up what lies in front of a tile from plain, cacheable words written by the kernel BEFORE it (no communication between
+            // the fill's blocks: that cost 15 us on the QM9-shaped batch, see ugs_fill_scan).  Rows are taken by index here (no
+            // list of handed-on rows: the host asks for the sums only when no walk can be handed on).
             for (int64_t it0 = (int64_t)blockIdx.x * GROUPS; it0 < total; it0 += ngroups) {
                 const int64_t it = it0 + gib;
-                if constexpr (GC) {
-                    const int64_t row0 = a.row_begin + it0;
-                    const int64_t gi0 = a.plan.num_graphs == 1 ? 0 : row0 / a.m;
-                    if (gi0 != cached) {                                                 // block-uniform
-                        __syncthreads();                                                  // nobody reads the old copy any more
-                        const UgsGraphDesc gd0 = a.plan.graphs[gi0];
-                        cached = gi0;
-                        gc.gi = -1;
-                        if (gd0.level >= 0 && gd0.n <= kGcMaxN) {
-                            const int64_t a0 = a.plan.rowptr[gd0.rbase], nnz = a.plan.rowptr[gd0.rbase + gd0.n] - a0;
-                            if (nnz <= kGcMaxE) {
-                                for (int x = (int)threadIdx.x; x <= gd0.n; x += BLOCK) c_rp[x] = a.plan.rowptr[gd0.rbase + x];
-                                for (int e = (int)threadIdx.x; e < (int)nnz; e += BLOCK) c_adj[e] = a.plan.adj[a0 + e];
-                                gc.rowptr = reinterpret_cast<const int64_t *>(reinterpret_cast<uintptr_t>(c_rp) - (uintptr_t)gd0.rbase * sizeof(int64_t));
-                                gc.adj = reinterpret_cast<const int2 *>(reinterpret_cast<uintptr_t>(c_adj) - (uintptr_t)a0 * sizeof(int2));
-                                gc.roots = a.plan.roots;
-                                if (gd0.level == 0) {                                     // the alias rows (relaxed levels keep their viable list in HBM)
-                                    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.plan.roots + gd0.vbase);
-                                    for (int x = (int)threadIdx.x; x < 3 * gd0.n; x += BLOCK) c_roots[x] = src[x];
-                                    gc.roots = reinterpret_cast<const UgsRootRec *>(reinterpret_cast<uintptr_t>(c_roots) - (uintptr_t)gd0.vbase * sizeof(UgsRootRec));
-                                }
-                                gc.gi = gi0;
-                            }
-                        }
-                        __syncthreads();
-                    }
-                }
                 uint32_t ne = 0u;
-                if (it < total) (void)do_walk<GS, LdsSpace, (CAP + GS - 1) / GS, PAD, GC>(ws, g, a, it, SV, EL, &ne, &gc);
-                if (a.wsum) {
-                    uint32_t sum = g.lane == 0 ? ne : 0u;
-                    sum += __shfl_xor(sum, 8, 64); sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
-                    const int64_t w0 = it0 + (int64_t)((threadIdx.x >> 6) * 8);      // first row of this wave
-                    if ((threadIdx.x & 63) == 0 && w0 < total) a.wsum[w0 >> 3] = sum;
-                }
+                if (it < total) (void)do_walk<GS, LdsSpace, (CAP + GS - 1) / GS, PAD>(ws, g, a, it, SV, EL, &ne);
+                uint32_t sum = g.lane == 0 ? ne : 0u;
+                sum += __shfl_xor(sum, 8, 64); sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+                const int64_t w0 = it0 + (int64_t)((threadIdx.x >> 6) * 8);          // first row of this wave
+                if ((threadIdx.x & 63) == 0 && w0 < total) a.wsum[w0 >> 3] = sum;
             }
             return;
         }
@@ -1698,14 +1651,14 @@ __global__ __launch_bounds__(kScanWide) void ugs_scan_small(const uint32_t *coun
 // written with the endpoint numbering of the mode.  The sample's vertices come from the nodes row (`nrow`, batch ids) or, when
 // the caller still has them in LDS, from `SVsrc` (graph-local ids).  SV / PS / R0: group-private LDS scratch.
 template <int GS>
-__device__ __forceinline__ void fill_row(const UgsFillArgs &a, const UgsPlanDev &P, const Grp<GS> &g, const UgsGraphDesc &gd, int64_t row_rel, int64_t i,
+__device__ __forceinline__ void fill_row(const UgsFillArgs &a, const int64_t *rowptr, const int2 *adjf, const Grp<GS> &g, const UgsGraphDesc &gd, int64_t row_rel, int64_t i,
                                          int64_t e0, const int64_t *nrow, const uint32_t *SVsrc, uint32_t *SV, uint32_t *PS, int64_t *R0) {
     const int k = a.k;
     const int64_t off = gd.node_lo + a.extra_node_off;
     LdsSpace::sync();
     for (int j = g.lane; j < k; j += GS) {
         const uint32_t u = nrow ? (uint32_t)(nrow[j] - off) : SVsrc[j];
-        const int64_t r0 = P.rowptr[gd.rbase + u], r1 = P.rowptr[gd.rbase + u + 1];
+        const int64_t r0 = rowptr[gd.rbase + u], r1 = rowptr[gd.rbase + u + 1];
         SV[j] = u;
         R0[j] = r0;
         PS[j + 1] = (uint32_t)(r1 - r0);
@@ -1736,7 +1689,7 @@ __device__ __forceinline__ void fill_row(const UgsFillArgs &a, const UgsPlanDev 
 #pragma unroll
                     for (int t = 1; t < 8; ++t) base_e = (j == t) ? ps[t] : base_e;
                     jj[u] = j;
-                    const int2 nb = P.adjf[R0[j] + (int64_t)(e - base_e)];          // neighbour and its edge column together
+                    const int2 nb = adjf[R0[j] + (int64_t)(e - base_e)];          // neighbour and its edge column together
                     wv[u] = (uint32_t)nb.x;
                     ec[u] = nb.y;
                 }
@@ -1776,7 +1729,7 @@ __device__ __forceinline__ void fill_row(const UgsFillArgs &a, const UgsPlanDev 
                 int j = 0;
                 for (int t = 1; t < k; ++t) j += (PS[t] <= e) ? 1 : 0;       // row of flattened entry e
                 jj[u] = j;
-                const int2 nb = P.adjf[R0[j] + (int64_t)(e - PS[j])];
+                const int2 nb = adjf[R0[j] + (int64_t)(e - PS[j])];
                 wv[u] = (uint32_t)nb.x;
                 ec[u] = nb.y;
             }
@@ -1830,7 +1783,7 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
         else { gi = row / a.m; i = row - gi * a.m; }
         const UgsGraphDesc gd = P.graphs[gi];
         const int64_t *nrow = a.nodes + row_rel * k;
-        fill_row<GS>(a, P, g, gd, row_rel, i, e0, nrow, nullptr, SV, PS, R0);
+        fill_row<GS>(a, P.rowptr, P.adjf, g, gd, row_rel, i, e0, nrow, nullptr, SV, PS, R0);
     }
 }
 
@@ -1896,7 +1849,7 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill_scan(UgsFillArgs a) {
             if (P.num_graphs == 1) { gi = 0; i = row; }
             else { gi = row / a.m; i = row - gi * a.m; }
             const UgsGraphDesc gd = P.graphs[gi];
-            fill_row<GS>(a, P, g, gd, row_rel, i, e0, a.nodes + row_rel * k, nullptr, SV, PS, R0);
+            fill_row<GS>(a, P.rowptr, P.adjf, g, gd, row_rel, i, e0, a.nodes + row_rel * k, nullptr, SV, PS, R0);
         }
         __syncthreads();
     }
@@ -1941,14 +1894,6 @@ static hipError_t launch_lds(const UgsWalkArgs &a, int cus, int blocks_per_cu, h
     const int64_t cap = (int64_t)cus * blocks_per_cu;
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
-    if constexpr (GS == 8) {
-        if (a.graph_cache == 1 && !a.in_list && !a.work_next) {            // batches of small graphs: the block keeps the graph of its rows in LDS
-            hipLaunchKernelGGL((ugs_walk_lds<GS, CAP, BLOCK, false, true>), dim3((unsigned)grid), dim3(BLOCK), 0, s, a);
-            if (info) { info->name = "ugs_walk_lds<8,64,gc>"; info->grid = (int)grid; info->block = BLOCK;
-                        info->lds_bytes = GROUPS * TierCfg<CAP>::WORDS * 4 + (kGcMaxN + 1) * 8 + kGcMaxE * 8 + kGcMaxN * 24; }
-            return hipGetLastError();
-        }
-    }
     if (kCanPad && a.plan.prow) hipLaunchKernelGGL((ugs_walk_lds<GS, CAP, BLOCK, kCanPad>), dim3((unsigned)grid), dim3(BLOCK), 0, s, a);
     else hipLaunchKernelGGL((ugs_walk_lds<GS, CAP, BLOCK, false>), dim3((unsigned)grid), dim3(BLOCK), 0, s, a);
     if (info) { info->name = name; info->grid = (int)grid; info->block = BLOCK; info->lds_bytes = GROUPS * TierCfg<CAP>::WORDS * 4; }
@@ -1967,7 +1912,7 @@ hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, int share_pe
     // collation, RCCL) find registers, LDS and wave slots on every CU while a walk is running (a full grid holds them to its end)
     auto part = [&](int blocks) { const int b = (int)((long long)blocks * (share_percent <= 0 || share_percent > 100 ? 100 : share_percent) / 100); return b < 1 ? 1 : b; };
     switch (tier) {
-    case UGS_TIER_S: return launch_lds<8, 64, 256>(a, cus, part(a.graph_cache == 1 && !a.in_list && !a.work_next ? 2 : UGS_BLOCKS_S), s, info, "ugs_walk_lds<8,64>");
+    case UGS_TIER_S: return launch_lds<8, 64, 256>(a, cus, part(UGS_BLOCKS_S), s, info, "ugs_walk_lds<8,64>");
     // one walk per wave: two walks per wave (GS 32) measured 26.4 ms vs 18.7 ms per 1M walks on C5 (two chunks per row)
     // resident one-wave blocks per CU: LDS is granted in 1280-byte granules (128 per CU) -- 7648 B = 6 granules -> 21 blocks, of
     // which the register budget (96 VGPRs: 5 waves per SIMD) admits 20; 19.5 KB = 16 granules -> 8; 38.9 KB = 31 granules -> 4
