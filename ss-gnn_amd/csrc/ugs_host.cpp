@@ -1130,12 +1130,12 @@ int graph_dev_roots(Graph &g, int dev, RootArena *ar, hipStream_t s, Graph::DevR
 
 // UGS_DEVICE_BATCH: 0 = never, 1 = whenever applicable, unset = whenever applicable and the batch has at least
 // kBatchPassMinCols columns.  The chain upload -> kernel -> keys back costs ~20 us of latencies whatever the size (round 4: the host
-// polls the kernel's completion word instead of waiting on the stream, -5 us).  Around 1200 columns (MUTAG- / QM9-shaped batches of
-// 32 graphs) that now ties with the host's own pass + plan assembly for host-visible outputs (0.115 against 0.114 ms, 0.699 against
-// 0.698 ms per call) and wins or ties with device outputs (0.163 against 0.179 ms, 0.111 against 0.111 ms); at 4672 columns
-// (PROTEINS-shaped) the pass wins both (0.265 against 0.278 ms).  Below ~1000 columns the host's pass over the columns is a few
-// microseconds and no chain of device latencies can tie with it: the default keeps such batches on the host.
-constexpr int64_t kBatchPassMinCols = 1024;
+// polls the kernel's completion word instead of waiting on the stream, -5 us).  Measured with the two paths taking turns call by call
+// (tools/batch_pass_probe.py, medians of 55 calls each, host-visible / device outputs): 4672 columns (PROTEINS-shaped) 0.261 / 0.175
+// against 0.279 / 0.187 ms for the host's own pass + plan assembly: the pass wins; ~1200 columns (QM9- / MUTAG-shaped batches of 32
+// graphs) 0.772 / 0.193 against 0.742 / 0.177 ms and 0.134 / 0.135 against 0.118 / 0.119 ms: it still loses ~16 us.  (Sequential
+// measurements -- first one path, then the other -- had shown a tie there: the order of the two had favoured the second.)
+constexpr int64_t kBatchPassMinCols = 2048;
 int device_batch_mode() {
     const char *e = std::getenv("UGS_DEVICE_BATCH");
     if (e && e[0] == '0') return 0;

@@ -89,7 +89,7 @@ def _run(calls, env):
 
 @pytest.mark.parametrize("env", [("1",), ("0",), (None, "0", "1")])
 def test_random_minibatches_through_the_device_pass(env):
-    """pass forced wherever it applies, pass off, and calls alternating between default (pass from 1024 columns on), off and forced
+    """pass forced wherever it applies, pass off, and calls alternating between default (pass from 2048 columns on), off and forced
     over ONE LRU history"""
     import ugs_sampler
     rng = random.Random(31337)

@@ -22,11 +22,22 @@ for name in ("c3_proteins_b8192", "c4_qm9_b65536", "c2_mutag_b1024"):
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / len(batches) * 1e3
     run(mk(5)); run(mk(5), device=dev)
+    # interleaved: the two paths take turns call by call (each call a batch of its own, timed on its own), medians -- a drift of the
+    # box or of the allocator cannot favour one of them
     res = {}
-    for tag, env in (("pass", None), ("general", "0")):
-        if env is None: os.environ.pop("UGS_DEVICE_BATCH", None)
-        else: os.environ["UGS_DEVICE_BATCH"] = env
-        res[tag] = (run(mk(20)), run(mk(20), device=dev))
+    for kw_tag, kw in (("host", {}), ("dev", {"device": dev})):
+        ts = {"pass": [], "general": []}
+        for e in mk(120):
+            tag = "pass" if len(ts["pass"]) <= len(ts["general"]) else "general"
+            os.environ["UGS_DEVICE_BATCH"] = "1" if tag == "pass" else "0"
+            t = time.perf_counter()
+            o = ugs_sampler.sample_batch(e, ptr_t, m, k, mode="sample", seed=42, **kw)
+            if kw: torch.cuda.synchronize()
+            ts[tag].append(time.perf_counter() - t)
+            del o
+        for tag in ts:
+            v = sorted(ts[tag][5:])
+            res.setdefault(tag, []).append(v[len(v) // 2] * 1e3)
     os.environ.pop("UGS_DEVICE_BATCH", None)
     rep = torch.from_numpy(ei)
     t = time.perf_counter()
