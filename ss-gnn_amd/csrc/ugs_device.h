@@ -65,7 +65,7 @@ struct UgsWalkArgs {
     int32_t m;               // samples per graph
     int32_t k;
     int32_t mode;            // UGS_MODE_* / UGS_EDGE_* (0 local, 1 flat, 2 global)
-    int32_t pad;
+    int32_t pad;             // UGS_SMALL_CAP: first-tier launch of tier S in its 32-candidate form
     int64_t extra_node_off;  // handle API "global": base_offset
     uint64_t seed64;         // (uint64_t)(int64_t)seed
     const uint64_t *seed_ptr;// if not NULL the seed is read from here (captured HIP graphs: the value changes between replays)
@@ -136,6 +136,9 @@ enum { UGS_TIER_S = 0 /* cap 64, 8 lanes */, UGS_TIER_M = 1 /* cap 448, 64 lanes
 static constexpr int UGS_TIER_CAP[UGS_LDS_TIERS] = {64, 448, 704, 1024, 1408, 2048};
 static constexpr int UGS_TIER_LANES[UGS_LDS_TIERS] = {8, 64, 64, 64, 64, 64};                // lanes per walk
 static constexpr int UGS_TIER_HASH_LIMIT[UGS_LDS_TIERS] = {96, 448, 896, 1536, 1792, 3072};  // TierCfg<CAP>::HLIMIT (static_assert in ugs_kernels.hip)
+// a form of tier S with half the workspace, for plans whose walks cannot hold more than 32 candidates (UgsWalkArgs::pad = UGS_SMALL_CAP)
+#define UGS_SMALL_CAP 32
+#define UGS_SMALL_HASH_LIMIT 48
 
 hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int device_cus, int share_percent, hipStream_t s, UgsLaunchInfo *info);
 hipError_t ugs_launch_build_prow(const UgsPlanDev &plan, int64_t num_vertices, int2 *prow, int shift, int device_cus, hipStream_t s);

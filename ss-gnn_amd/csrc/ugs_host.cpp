@@ -485,7 +485,8 @@ void pool_put(PoolBuf &b) {
 // ---------------------------------------------------------------------------------------------------------------
 // plans
 // ---------------------------------------------------------------------------------------------------------------
-struct TierChoice { int first = UGS_TIER_S; int second = -1 /* LDS tier that redoes the rows the first one hands on */; bool third_G = false; int64_t bound = 0; };
+struct TierChoice { int first = UGS_TIER_S; int second = -1 /* LDS tier that redoes the rows the first one hands on */; bool third_G = false; int64_t bound = 0;
+                    bool small = false /* tier S in its 32-candidate form */; };
 
 struct ugs_plan {
     int device = -1, cus = 256;
@@ -926,6 +927,10 @@ TierChoice choose_tier(ugs_plan *p, int k) {
     }
     const int last_lds = t.second >= 0 ? t.second : t.first;
     t.third_G = may_hand_on(last_lds);
+    // tier S in its 32-candidate form: only where no walk can outgrow it (candidate bound, and the hash guard: seen vertices + the
+    // 8 lanes of a chunk), so that it needs no hand-on chain of its own
+    t.small = t.first == UGS_TIER_S && bound <= UGS_SMALL_CAP && bound + 1 + UGS_TIER_LANES[UGS_TIER_S] <= UGS_SMALL_HASH_LIMIT &&
+              std::getenv("UGS_NO_SMALL_TIER") == nullptr;
     p->tiers[k] = t;
     return t;
 }
@@ -1835,6 +1840,7 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
         plan->stg_m = m_per_graph; plan->stg_k = k;
     }
     a.work_next = dyn ? static_cast<unsigned long long *>(plan->work.p) + 0 : nullptr;
+    if (tc.small) a.pad = UGS_SMALL_CAP;
     // ugs_plan_step: the fill kernel can turn the counts into edge_ptr itself when the walk leaves the sums of 8 rows beside them --
     // 8-lane tier, rows taken by index (static split), no walk handed on, no capture in progress, a row count the fill's blocks can
     // add up in a few dozen loads per thread

@@ -739,7 +739,7 @@ __device__ __forceinline__ Pick stage_final(const Work<LdsSpace> &ws, const Grp<
 // waits on them), the elements-per-lane variant of a materialising stage is fixed at compile time, and a final stage only
 // carries the variants its candidate range (B[stage-1], min(B[stage], CAP)] can need.
 constexpr int nj_of(int per) { return per <= 1 ? 1 : per <= 3 ? 3 : per <= 5 ? 5 : per <= 7 ? 7 : per <= 9 ? 9 : per <= 13 ? 13 : per <= 17 ? 17 : per <= 19 ? 19 : 33; }
-constexpr int nst_of(int cap) { return cap <= 64 ? 3 : (cap <= 512 ? 5 : (cap <= 1024 ? 6 : 7)); }       // stages that are ever materialised
+constexpr int nst_of(int cap) { return cap <= 32 ? 2 : (cap <= 64 ? 3 : (cap <= 512 ? 5 : (cap <= 1024 ? 6 : 7))); }       // stages that are ever materialised
 // Bucket-table words of a tier.  Normally the smallest chain value >= CAP (the final stage's buckets in one piece).  The 704-candidate
 // tier keeps only HALF of its final stage's 1109 + 1 slots (stage_final runs two passes there) and lets the 541-bucket stage put its
 // position lists into its own order array: 11.6 KB per walk instead of 19.4 KB, 12 walks per CU instead of 8.
@@ -748,7 +748,8 @@ constexpr int nst_of(int cap) { return cap <= 64 ? 3 : (cap <= 512 ? 5 : (cap <=
 constexpr int tier_index(int cap) { return cap <= 64 ? 0 : (cap <= 512 ? 1 : (cap <= 704 ? 2 : (cap <= 1024 ? 3 : (cap <= 1408 ? 4 : 5)))); }
 // (The same diet for the 1024-candidate tier -- 17.2 KB, 9 walks per CU instead of 8 -- measured slower: 50.9 against 52.0 M/s on
 // degree 160, k = 6: one more resident walk does not pay for the second pass of every final stage above 541 candidates.)
-constexpr int tbl_words(int cap) { constexpr int w[6] = {127, 541, 555, 1109, 1109, 2357}; return (w[tier_index(cap)] + 3) & ~3; }
+// (The 32-candidate form of the 8-lane tier -- batches of graphs of at most 33 vertices, QM9- and MUTAG-sized -- ends at the 59-bucket stage.)
+constexpr int tbl_words(int cap) { constexpr int w[6] = {127, 541, 555, 1109, 1109, 2357}; return ((cap <= 32 ? 59 : w[tier_index(cap)]) + 3) & ~3; }
 
 template <int STAGE> struct ChainAt {
     static constexpr uint32_t B = kChainHost[STAGE], M = cmagic(kChainHost[STAGE]), S = (uint32_t)clog2(kChainHost[STAGE]) - 1u;
@@ -1376,10 +1377,12 @@ template <int CAP> struct TierCfg {
     static constexpr int ORDW = (int)(((ord_words_before(NSTAGE) + 1u) / 2u + 3u) & ~3u);   // 16-bit positions: 52 / 248 / 520 / 1072 words
     static constexpr int TI = tier_index(CAP);
     static constexpr int BCAP_A = tbl_words(CAP);                                   // bucket-table words (see tbl_words)
-    static constexpr int HS = TI == 0 ? 128 : (TI == 1 ? 512 : (TI == 2 ? 1024 : (TI <= 4 ? 2048 : 4096)));
+    static constexpr int HS = CAP <= 32 ? 64 : (TI == 0 ? 128 : (TI == 1 ? 512 : (TI == 2 ? 1024 : (TI <= 4 ? 2048 : 4096))));
     static constexpr int HLIMIT = (TI == 1 || TI == 2 || TI == 4) ? HS / 8 * 7 : HS / 4 * 3;   // max distinct vertices a walk may have seen
     static_assert(CAP <= 64 || BCAP_A * 4 >= 127 * 16, "mates2_by_table keeps 16 bytes per bucket of the 127-bucket stage in TBL");
-    static_assert(HLIMIT == UGS_TIER_HASH_LIMIT[TI] && CAP == UGS_TIER_CAP[TI], "host tier logic (choose_tier) relies on these limits");
+    // (CAP 32 is a form of tier S the host picks only for walks that cannot outgrow it: UGS_SMALL_CAP / UGS_SMALL_HASH_LIMIT)
+    static_assert(CAP == UGS_SMALL_CAP ? HLIMIT == UGS_SMALL_HASH_LIMIT : (HLIMIT == UGS_TIER_HASH_LIMIT[TI] && CAP == UGS_TIER_CAP[TI]),
+                  "host tier logic (choose_tier) relies on these limits");
     static constexpr int ELW = CAP > 64 ? 4 * UGS_STAGE_ENTRIES : 0;             // staged hits (one-walk-per-wave tiers)
     static constexpr int WORDS = CAP /*D*/ + ORDW + BCAP_A /*TBL*/ + HS /*HK*/ + UGS_KMAX /*SV*/ + ELW;
 };
@@ -1390,7 +1393,7 @@ template <int CAP> struct TierCfg {
 // (10.63 vs 10.43 ms: a launch ended with the waves of the fuller SIMDs); with the shared work counter the extra waves are
 // pure throughput: 8.81 -> 8.51 ms.  Spilling further to reach more waves costs more than it brings (30 % in an early build).
 template <int GS, int CAP, int BLOCK, bool PAD>
-__global__ __launch_bounds__(BLOCK, (CAP > 64 && CAP <= 512) ? 5 : (CAP == 704 ? 3 : (CAP <= 64 || CAP == 1024 || CAP == 1408 ? 2 : 1))) void ugs_walk_lds(UgsWalkArgs a) {
+__global__ __launch_bounds__(BLOCK, CAP <= 32 ? 4 : ((CAP > 64 && CAP <= 512) ? 5 : (CAP == 704 ? 3 : (CAP <= 64 || CAP == 1024 || CAP == 1408 ? 2 : 1)))) void ugs_walk_lds(UgsWalkArgs a) {
     using Cfg = TierCfg<CAP>;
     constexpr int GROUPS = BLOCK / GS;
     __shared__ __attribute__((aligned(16))) uint32_t lds[GROUPS * Cfg::WORDS];
@@ -1912,7 +1915,11 @@ hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, int share_pe
     // collation, RCCL) find registers, LDS and wave slots on every CU while a walk is running (a full grid holds them to its end)
     auto part = [&](int blocks) { const int b = (int)((long long)blocks * (share_percent <= 0 || share_percent > 100 ? 100 : share_percent) / 100); return b < 1 ? 1 : b; };
     switch (tier) {
-    case UGS_TIER_S: return launch_lds<8, 64, 256>(a, cus, part(UGS_BLOCKS_S), s, info, "ugs_walk_lds<8,64>");
+    case UGS_TIER_S:
+        // graphs of at most 33 vertices (QM9-, MUTAG-sized): 32 candidates per walk, 27 KB of LDS and 95 VGPRs per block -- five blocks
+        // per CU instead of three (the QM9-shaped batch of 65 536 rows takes two trips instead of three)
+        if (a.pad == UGS_SMALL_CAP && !a.in_list) return launch_lds<8, UGS_SMALL_CAP, 256>(a, cus, part(5), s, info, "ugs_walk_lds<8,32>");
+        return launch_lds<8, 64, 256>(a, cus, part(UGS_BLOCKS_S), s, info, "ugs_walk_lds<8,64>");
     // one walk per wave: two walks per wave (GS 32) measured 26.4 ms vs 18.7 ms per 1M walks on C5 (two chunks per row)
     // resident one-wave blocks per CU: LDS is granted in 1280-byte granules (128 per CU) -- 7648 B = 6 granules -> 21 blocks, of
     // which the register budget (96 VGPRs: 5 waves per SIMD) admits 20; 19.5 KB = 16 granules -> 8; 38.9 KB = 31 granules -> 4
