@@ -537,7 +537,7 @@ __device__ __forceinline__ Pick stage_final_reg(const Work<LdsSpace> &ws, const 
     const uint32_t key = ws.D[pos];
     const uint32_t rank = rank_in_registers(g, valid, mod_stage(key, B, M, S), ws.TBL, B);
     const uint64_t hm = __ballot(rank == rsel) & __ballot(valid);
-    const int src = hm ? (__ffsll((long long)hm) - 1) : 0;
+    const int src = __builtin_ctzll(hm);               // (some lane holds the rank: c >= 1, the mask is never empty)
     return Pick{g.bcast(key, src), g.bcast(pos, src)};
 }
 
@@ -698,17 +698,20 @@ __device__ __forceinline__ Pick stage_final(const Work<LdsSpace> &ws, const Grp<
     const uint32_t incl = g.prefix_incl(mine_total);
     uint32_t run = g.last(incl) - incl;                                   // positions taken by buckets led from higher lanes
     const uint32_t target = rsel + ((uint32_t)NJ - 1u - (L - 1u) % (uint32_t)NJ);   // only the lane that holds candidate L-1 enters its elements past L
-    bool hit = false;
-    uint32_t hb = 0u, ho = 0u;
+    // (no boolean is carried from slot to slot: an OR of lane predicates is a scalar instruction per slot -- the offset's sentinel
+    // says afterwards whether the lane holds the bucket)
+    uint32_t hb = 0u, ho = 0xFFFFFFFFu;
 #pragma unroll
     for (int j = NJ - 1; j >= 0; --j) {
         const uint32_t d = target - run;                                  // one unsigned compare: run <= target < run + size
         const bool h = d < gs[j];
-        hb = h ? bk[j] : hb; ho = h ? d : ho; hit |= h;
+        hb = h ? bk[j] : hb; ho = h ? d : ho;
         run += gs[j];
     }
-    const uint64_t hm = g.ballot(hit);
-    const int hsrc = hm ? (__ffsll((long long)hm) - 1) : 0;
+    const uint64_t hm = g.ballot(ho != 0xFFFFFFFFu);
+    // (a bucket holds the target rank and a member of it the offset: the masks are never empty; unguarded, the lane number is the
+    // find-first-set alone -- the `mask ? .. : 0` form costs a scalar compare and select each)
+    const int hsrc = GS == 64 ? __builtin_ctzll(hm) : (hm ? (__ffsll((long long)hm) - 1) : 0);
     const uint32_t bstar = g.bcast(hb, hsrc), off = g.bcast(ho, hsrc);
     // members of that bucket are visited in DESCENDING position: the answer has exactly `off` members above it.  Members in
     // higher lanes: the lane's own member count, suffix-summed over the lanes by ONE scan (not one ballot per element slot)
@@ -717,16 +720,15 @@ __device__ __forceinline__ Pick stage_final(const Work<LdsSpace> &ws, const Grp<
     for (int j = 0; j < NJ; ++j) { cj[j] = bk[j] == bstar ? 1u : 0u; own += cj[j]; }
     const uint32_t oincl = g.prefix_incl(own);
     uint32_t above = g.last(oincl) - oincl;
-    bool have = false;
-    uint32_t mine = 0u;
+    uint32_t mine = 0xFFFFFFFFu;
 #pragma unroll
     for (int j = NJ - 1; j >= 0; --j) {
-        const bool h = cj[j] != 0u && above == off;
-        mine = h ? pos[j] : mine; have |= h;
+        const uint32_t ab = cj[j] != 0u ? above : 0xFFFFFFFFu;           // a member of the bucket with exactly `off` members above it
+        mine = ab == off ? pos[j] : mine;
         above += cj[j];
     }
-    const uint64_t mk = g.ballot(have);
-    const int src = mk ? (__ffsll((long long)mk) - 1) : 0;
+    const uint64_t mk = g.ballot(mine != 0xFFFFFFFFu);
+    const int src = GS == 64 ? __builtin_ctzll(mk) : (mk ? (__ffsll((long long)mk) - 1) : 0);
     LdsSpace::sync();
     const uint32_t q = g.bcast(mine, src);
     return Pick{g.uni(ws.D[q]), q};
@@ -1247,8 +1249,14 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
 #define UGS_PAD1 asm volatile("v_mov_b32_e64 %0, 0" : "=v"(pad_));
 #elif UGS_PAD == 5      /* a conditional branch that is not taken */
 #define UGS_PAD1 asm volatile("s_cmp_eq_u32 0, 0\ns_cbranch_scc0 ugs_pad_%=\nugs_pad_%=:" : "=s"(pad_) : : "scc");
-#else                   /* a taken branch (to the next instruction) */
+#elif UGS_PAD == 6      /* a taken branch (to the next instruction) */
 #define UGS_PAD1 asm volatile("s_branch ugs_pad_%=\nugs_pad_%=:" : "=s"(pad_));
+#elif UGS_PAD == 7      /* the wait-state filler the compiler puts in front of DPP reads */
+#define UGS_PAD1 asm volatile("s_nop 0" : "=s"(pad_));
+#elif UGS_PAD == 8
+#define UGS_PAD1 asm volatile("s_nop 1" : "=s"(pad_));
+#else                   /* a counter wait with nothing outstanding */
+#define UGS_PAD1 asm volatile("s_waitcnt lgkmcnt(0)" : "=s"(pad_));
 #endif
 #define UGS_PAD8 UGS_PAD1 UGS_PAD1 UGS_PAD1 UGS_PAD1 UGS_PAD1 UGS_PAD1 UGS_PAD1 UGS_PAD1
             UGS_PAD8 UGS_PAD8 UGS_PAD8 UGS_PAD8 UGS_PAD8 UGS_PAD8 UGS_PAD8 UGS_PAD8
