@@ -242,6 +242,16 @@ template <int GS> struct Grp {
         }
         return x;
     }
+    // the same when only the first N lanes' sums are needed (GS == 64): 16 lanes are one DPP row -- no row broadcasts --, 32 need one
+    template <int N> __device__ __forceinline__ uint32_t prefix_incl_first(uint32_t x) const {
+        if (GS != 64 || N > 32) return prefix_incl(x);
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+        if (N > 16) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+        return x;
+    }
     // group-uniform values: with one walk per wave they are wave-uniform and belong in scalar registers
     __device__ __forceinline__ uint32_t uni(uint32_t x) const { return GS == 64 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)x) : x; }
     __device__ __forceinline__ int64_t uni(int64_t x) const {
@@ -442,7 +452,9 @@ __device__ __forceinline__ void stage_mat(const Work<LdsSpace> &ws, const Grp<GS
         mine_total += gs[j];
     }
     const uint32_t incl = g.prefix_incl(mine_total);
-    uint32_t run = g.last(incl) - incl;                                       // ranks taken by buckets led from higher lanes
+    // ranks taken by buckets led from higher lanes.  The sizes of all buckets add up to the stage's B elements: no read of the last
+    // lane's sum (a v_readlane behind a DPP step and in front of its first use costs two wait-state fillers; an s_nop is 5-8 wave-cycles)
+    uint32_t run = B - incl;
     LdsSpace::sync();                                                          // every lane has read the sizes
 #pragma unroll
     for (int j = NJ - 1; j >= 0; --j) {
@@ -493,7 +505,8 @@ __device__ __forceinline__ void stage_mat(const Work<LdsSpace> &ws, const Grp<GS
 // one DPP scan of the sizes over the leaders gives every bucket's start and one ds_bpermute fetches the leader's start.
 // rank = start + members above -- the same definition as stage_mat.
 
-__device__ __forceinline__ uint32_t rank_in_registers(const Grp<64> &g, bool valid, uint32_t bk, uint32_t *TBL, uint32_t B) {
+template <int MAXN = 64>      // MAXN: compile-time bound on the valid lanes (the 13- and 29-element stages scan one or two DPP rows only)
+__device__ __forceinline__ uint32_t rank_in_registers(const Grp<64> &g, bool valid, uint32_t bk, uint32_t *TBL, uint32_t B, uint32_t n_valid) {
     // mask of the lane's bucket-mates through the (otherwise idle) bucket table: one 64-bit member mask per bucket, set by an
     // LDS atomic OR and read back -- one LDS round trip in place of a radix pass of ballots over the bits of the bucket number
     // (4 vector instructions per bit: 62-78 -> 37-41 per stage).  B <= 127: a final of <= 64 candidates may have 127 buckets.
@@ -506,15 +519,18 @@ __device__ __forceinline__ uint32_t rank_in_registers(const Grp<64> &g, bool val
     LdsSpace::sync();
     const uint64_t mates = T8[bk];
     const uint32_t size = (uint32_t)__popcll(mates);
-    const uint32_t above = (uint32_t)__popcll(mates & (~1ull << g.lane));
-    const uint32_t first = valid ? (uint32_t)(__ffsll((long long)mates) - 1) : (uint32_t)g.lane;
+    // members above the lane = size - 1 - members below it: v_mbcnt counts those in two instructions (the mask of the higher lanes
+    // takes a 64-bit shift and two ANDs first)
+    const uint32_t above = size - 1u - g.below(mates);
+    const uint32_t first = valid ? (uint32_t)__builtin_ctzll(mates) : (uint32_t)g.lane;   // (a valid lane's mask holds its own bit: no zero guard)
     const uint32_t lead = (valid && first == (uint32_t)g.lane) ? size : 0u;
-    const uint32_t incl = g.prefix_incl(lead);
-    const uint32_t run = g.last(incl) - incl;                              // ranks taken by buckets led from higher lanes
+    const uint32_t incl = g.template prefix_incl_first<MAXN>(lead);
+    const uint32_t run = n_valid - incl;                                   // ranks taken by buckets led from higher lanes (the sizes add up to the valid elements)
     const uint32_t start = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(first << 2), (int)run);
     return start + above;
 }
 
+template <int MAXN = 64>
 __device__ __forceinline__ void stage_mat_reg(const Work<LdsSpace> &ws, const Grp<64> &g, const uint16_t *OLD, uint16_t *NEW,
                                               uint32_t n_old, uint32_t B, uint32_t M, uint32_t S) {
     const uint32_t t = (uint32_t)g.lane;
@@ -523,11 +539,12 @@ __device__ __forceinline__ void stage_mat_reg(const Work<LdsSpace> &ws, const Gr
     uint32_t pos = t;
     if (n_old) { const uint32_t o = OLD[t]; pos = t < n_old ? o : t; }
     const uint32_t key = ws.D[pos];
-    const uint32_t rank = rank_in_registers(g, valid, mod_stage(key, B, M, S), ws.TBL, B);
+    const uint32_t rank = rank_in_registers<MAXN>(g, valid, mod_stage(key, B, M, S), ws.TBL, B, B);
     if (valid) NEW[rank] = (uint16_t)pos;
     LdsSpace::sync();
 }
 
+template <int MAXN = 64>
 __device__ __forceinline__ Pick stage_final_reg(const Work<LdsSpace> &ws, const Grp<64> &g, const uint16_t *OLD, uint32_t n_old,
                                                 uint32_t L, uint32_t B, uint32_t M, uint32_t S, uint32_t rsel) {
     const uint32_t t = (uint32_t)g.lane;
@@ -535,8 +552,9 @@ __device__ __forceinline__ Pick stage_final_reg(const Work<LdsSpace> &ws, const 
     uint32_t pos = t;
     if (n_old) { const uint32_t o = OLD[t]; pos = t < n_old ? o : t; }
     const uint32_t key = ws.D[pos];
-    const uint32_t rank = rank_in_registers(g, valid, mod_stage(key, B, M, S), ws.TBL, B);
-    const uint64_t hm = __ballot(rank == rsel) & __ballot(valid);
+    const uint32_t rank = rank_in_registers<MAXN>(g, valid, mod_stage(key, B, M, S), ws.TBL, B, L);
+    // (the valid lanes' mask by scalar arithmetic: a ballot of `valid`, a compare computed blocks earlier, is rebuilt from a 0/1 vector)
+    const uint64_t hm = __ballot(rank == rsel) & (~0ull >> (64u - L));                  // 1 <= L <= 64
     const int src = __builtin_ctzll(hm);               // (some lane holds the rank: c >= 1, the mask is never empty)
     return Pick{g.bcast(key, src), g.bcast(pos, src)};
 }
@@ -568,13 +586,13 @@ __device__ __forceinline__ Rank2 rank2_from_mates(const Grp<64> &g, bool valid1,
     const uint64_t gt = ~1ull << g.lane;
     const uint32_t lane = (uint32_t)g.lane;
     // element in slot 0: its bucket's leader is the lowest slot-0 mate (itself included)
-    const uint32_t first0 = (uint32_t)(__ffsll((long long)m00) - 1);
+    const uint32_t first0 = (uint32_t)__builtin_ctzll(m00);                // (holds the element's own bit)
     const uint32_t size0 = (uint32_t)(__popcll(m00) + __popcll(m01));
     const uint32_t above0 = (uint32_t)(__popcll(m00 & gt) + __popcll(m01));
     const uint32_t lead0 = first0 == lane ? size0 : 0u;
     // element in slot 1: led from slot 0 if it has a mate there, else by the lowest slot-1 mate
     const bool from0 = m10 != 0ull;
-    const uint32_t first1 = valid1 ? (uint32_t)(__ffsll((long long)(from0 ? m10 : m11)) - 1) : lane;
+    const uint32_t first1 = valid1 ? (uint32_t)__builtin_ctzll(from0 ? m10 : m11) : lane;   // (m11 holds a valid element's own bit)
     const uint32_t above1 = (uint32_t)__popcll(m11 & gt);
     const uint32_t lead1 = (valid1 && !from0 && first1 == lane) ? (uint32_t)__popcll(m11) : 0u;
     // both prefix sums in ONE scan: the sums stay below 2^16 (at most 128 elements), slot 1 rides in the upper half
@@ -647,17 +665,13 @@ __device__ __forceinline__ Pick stage_final(const Work<LdsSpace> &ws, const Grp<
             const uint32_t m = mod_stage(key[j], B, M, S);
             bk[j] = t0 + j < L ? m : B;
         }
-        if constexpr (PASSES == 1) {
-            if (t0 < L) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) atomicMin(&ws.TBL[bk[j]], t0 + j);
-            }
-        }
     }
     uint32_t gs[NJ], mine_total = 0u;
     if constexpr (PASSES == 1) {
-        LdsSpace::sync();
-        if (t0 < L) {
+        if (t0 < L) {                                                          // (both atomics under ONE saved mask)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) atomicMin(&ws.TBL[bk[j]], t0 + j);
+            LdsSpace::sync();
 #pragma unroll
             for (int j = 0; j < NJ; ++j) atomicAdd(&ws.TBL[bk[j]], 0x10000u);
         }
@@ -696,36 +710,49 @@ __device__ __forceinline__ Pick stage_final(const Work<LdsSpace> &ws, const Grp<
         mine_total += gs[j];
     }
     const uint32_t incl = g.prefix_incl(mine_total);
-    uint32_t run = g.last(incl) - incl;                                   // positions taken by buckets led from higher lanes
-    const uint32_t target = rsel + ((uint32_t)NJ - 1u - (L - 1u) % (uint32_t)NJ);   // only the lane that holds candidate L-1 enters its elements past L
+    const uint32_t past = (uint32_t)NJ - 1u - (L - 1u) % (uint32_t)NJ;    // only the lane that holds candidate L-1 enters its elements past L
+    uint32_t run = (L + past) - incl;                                     // positions taken by buckets led from higher lanes (all sizes together: the elements entered)
+    const uint32_t target1 = rsel + past + 1u;
     // (no boolean is carried from slot to slot: an OR of lane predicates is a scalar instruction per slot -- the offset's sentinel
     // says afterwards whether the lane holds the bucket)
     uint32_t hb = 0u, ho = 0xFFFFFFFFu;
 #pragma unroll
     for (int j = NJ - 1; j >= 0; --j) {
-        const uint32_t d = target - run;                                  // one unsigned compare: run <= target < run + size
-        const bool h = d < gs[j];
-        hb = h ? bk[j] : hb; ho = h ? d : ho;
         run += gs[j];
+        const uint32_t e = run - target1;                                 // one unsigned compare: run - size <= target < run; e = members of the bucket BELOW the answer
+        const bool h = e < gs[j];
+        hb = h ? bk[j] : hb; ho = h ? e : ho;
     }
     const uint64_t hm = g.ballot(ho != 0xFFFFFFFFu);
     // (a bucket holds the target rank and a member of it the offset: the masks are never empty; unguarded, the lane number is the
     // find-first-set alone -- the `mask ? .. : 0` form costs a scalar compare and select each)
     const int hsrc = GS == 64 ? __builtin_ctzll(hm) : (hm ? (__ffsll((long long)hm) - 1) : 0);
     const uint32_t bstar = g.bcast(hb, hsrc), off = g.bcast(ho, hsrc);
-    // members of that bucket are visited in DESCENDING position: the answer has exactly `off` members above it.  Members in
-    // higher lanes: the lane's own member count, suffix-summed over the lanes by ONE scan (not one ballot per element slot)
-    uint32_t cj[NJ], own = 0u;
+    // members of that bucket are visited in DESCENDING position: the answer has exactly `off` members BELOW it (counted from below,
+    // the prefix sum needs no total).  Members in lower lanes: the lane's own member count, summed over the lanes by ONE scan (not
+    // one ballot per element slot)
+    uint32_t cj[NJ], below = 0u;
+    if constexpr (GS == 64) {
+        // one walk per wave: the members in lower lanes are counted from the slots' ballots -- two v_mbcnt per slot, each adding to
+        // the running count -- where a DPP scan of the lanes' own counts took six steps with a wait-state filler behind each
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) { cj[j] = bk[j] == bstar ? 1u : 0u; own += cj[j]; }
-    const uint32_t oincl = g.prefix_incl(own);
-    uint32_t above = g.last(oincl) - oincl;
+        for (int j = 0; j < NJ; ++j) {
+            cj[j] = bk[j] == bstar ? 1u : 0u;
+            const uint64_t mj = __ballot(bk[j] == bstar);
+            below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mj >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mj, below));
+        }
+    } else {
+        uint32_t own = 0u;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { cj[j] = bk[j] == bstar ? 1u : 0u; own += cj[j]; }
+        below = g.prefix_incl(own) - own;
+    }
     uint32_t mine = 0xFFFFFFFFu;
 #pragma unroll
-    for (int j = NJ - 1; j >= 0; --j) {
-        const uint32_t ab = cj[j] != 0u ? above : 0xFFFFFFFFu;           // a member of the bucket with exactly `off` members above it
-        mine = ab == off ? pos[j] : mine;
-        above += cj[j];
+    for (int j = 0; j < NJ; ++j) {
+        const uint32_t bl = cj[j] != 0u ? below : 0xFFFFFFFFu;           // a member of the bucket with exactly `off` members below it
+        mine = bl == off ? pos[j] : mine;
+        below += cj[j];
     }
     const uint64_t mk = g.ballot(mine != 0xFFFFFFFFu);
     const int src = GS == 64 ? __builtin_ctzll(mk) : (mk ? (__ffsll((long long)mk) - 1) : 0);
@@ -769,7 +796,7 @@ __device__ __forceinline__ void mat_at(const Work<LdsSpace> &ws, const Grp<GS> &
     STAMP_SUB_BEGIN();
     // position lists behind the table only where the tier's table has the room (see tbl_words)
     constexpr bool POS_IN_NEW = (int)(((C::B + 3u) & ~3u) + (C::B + 1u) / 2u) > tbl_words(MAXPER * GS);
-    if constexpr (GS == 64 && per <= 1) stage_mat_reg(ws, g, OLD, NEW, C::NOLD, C::B, C::M, C::S);
+    if constexpr (GS == 64 && per <= 1) stage_mat_reg<(int)C::B>(ws, g, OLD, NEW, C::NOLD, C::B, C::M, C::S);
     // (for 65..128 elements the register ranking, 203 VALU instructions, still beats the bucket-table variant with 2 elements per
     // lane, 169 instructions but nine LDS round trips: 6.81 against 6.95 ms per 1M walks)
     else if constexpr (GS == 64 && per <= 2) stage_mat_reg2(ws, g, OLD, NEW, C::NOLD, C::B, C::M, C::S);
@@ -777,36 +804,57 @@ __device__ __forceinline__ void mat_at(const Work<LdsSpace> &ws, const Grp<GS> &
     STAMP_SUB_END(per <= 1 ? 10 : (per <= 2 ? 11 : 12));
 }
 
+// The variants of a final stage by elements per lane: variant i serves per <= var_hi(i) (and more than var_hi(i-1)) with var_nj(i)
+// element slots per lane (0: the register-ranked final of one walk per wave).  Which variant serves how many elements per lane
+// (measured on C5, VALU-bound at 20 waves/CU): up to 64 candidates the register-ranked final (78 VALU instructions against 59 + 7
+// LDS operations for the table variant: the shorter dependency chain wins); from 65 on the bucket-table variant with exactly
+// ceil(c/64) elements per lane -- for 65..128 candidates it takes 93 VALU instructions where ranking two elements per lane in
+// registers took 207 (7.16 -> 7.01 ms per 1M walks).
+template <int GS> constexpr int var_count() { return GS == 64 ? 13 : 10; }
+template <int GS> constexpr int var_hi(int i) {
+    constexpr int h64[13] = {1, 2, 3, 4, 5, 6, 7, 9, 11, 13, 17, 22, 1 << 20}, h8[10] = {1, 3, 5, 7, 9, 11, 13, 17, 22, 1 << 20};
+    return GS == 64 ? h64[i] : h8[i];
+}
+template <int GS> constexpr int var_nj(int i) {
+    constexpr int n64[13] = {0, 2, 3, 4, 5, 6, 7, 9, 11, 13, 17, 22, 33}, n8[10] = {1, 3, 5, 7, 9, 11, 13, 17, 22, 33};
+    return GS == 64 ? n64[i] : n8[i];
+}
+template <int GS> constexpr int var_first_with_hi_at_least(int per) { int i = 0; while (var_hi<GS>(i) < per) ++i; return i; }
+
+// the variant by a binary decision tree over the variant indices [I0, I1] the stage's candidate range can need: every leaf returns,
+// nothing follows the tree.  (A sequence of `if (per <= HI) return variant;` cases compiles into a chain in which every case BEHIND the
+// one taken is skipped by a flag test and a taken branch -- three scalar instructions and 18 wave-cycles of branch per skipped case.)
+template <int GS, int MAXPER, int STAGE, int I0, int I1>
+__device__ __forceinline__ Pick final_tree(const Work<LdsSpace> &ws, const Grp<GS> &g, int per, uint32_t c, uint32_t rsel) {
+    using C = ChainAt<STAGE>;
+    if constexpr (I0 == I1) {
+        const uint16_t *OLD = ws.ORD + C::OOLD;
+        constexpr uint32_t CAP = (uint32_t)(MAXPER * GS);
+        constexpr int NJ = var_nj<GS>(I0);
+        // the table holds the stage's slots 0 .. B in one piece, or a half / a third of them
+        constexpr int PASSES = ((int)C::B + tbl_words((int)CAP)) / tbl_words((int)CAP);
+        static_assert(((int)C::B + PASSES) / PASSES <= tbl_words((int)CAP), "a pass of the final stage must fit the tier's bucket table");
+        STAMP_SUB_BEGIN();
+        Pick r;
+        if constexpr (NJ == 0) r = stage_final_reg<(int)(C::B < 64u ? C::B : 64u)>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel);
+        else r = stage_final<GS, NJ, PASSES>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel);
+        STAMP_SUB_END(var_hi<GS>(I0) <= 1 ? 13 : (var_hi<GS>(I0) <= 2 ? 14 : 15));
+        return r;
+    } else {
+        constexpr int MID = (I0 + I1) / 2;
+        if (per <= var_hi<GS>(MID)) return final_tree<GS, MAXPER, STAGE, I0, MID>(ws, g, per, c, rsel);
+        return final_tree<GS, MAXPER, STAGE, MID + 1, I1>(ws, g, per, c, rsel);
+    }
+}
+
 template <int GS, int MAXPER, int STAGE>
 __device__ __forceinline__ Pick final_at(const Work<LdsSpace> &ws, const Grp<GS> &g, uint32_t c, uint32_t rsel) {
     using C = ChainAt<STAGE>;
-    const uint16_t *OLD = ws.ORD + C::OOLD;
     constexpr uint32_t CAP = (uint32_t)(MAXPER * GS);
+    // a final at this stage sees NOLD < c <= min(B, CAP) candidates: only the variants that range can need are instantiated
     constexpr int pmin = (int)((C::NOLD + 1u + GS - 1) / GS), pmax = (int)(((C::B < CAP ? C::B : CAP) + GS - 1) / GS);
     const int per = (int)((c + GS - 1) / GS);
-    // a variant serving per in [LO, HI] exists only if the stage's range meets it; the last one that does needs no test
-#ifdef UGS_STAMPS
-#define UGS_FINAL_CASE(LO, HI, CALL) if constexpr (pmin <= (HI) && pmax >= (LO)) { if (pmax <= (HI) || per <= (HI)) { STAMP_SUB_BEGIN(); const Pick r_ = CALL; STAMP_SUB_END((HI) <= 1 ? 13 : ((HI) <= 2 ? 14 : 15)); return r_; } }
-#else
-#define UGS_FINAL_CASE(LO, HI, CALL) if constexpr (pmin <= (HI) && pmax >= (LO)) { if (pmax <= (HI) || per <= (HI)) return CALL; }
-#endif
-    // Which variant serves how many elements per lane (measured on C5, VALU-bound at 20 waves/CU): up to 64 candidates the
-    // register-ranked final (78 VALU instructions against 59 + 7 LDS operations for the table variant: the shorter dependency
-    // chain wins); from 65 on the bucket-table variant with exactly ceil(c/64) elements per lane -- for 65..128 candidates it
-    // takes 93 VALU instructions where ranking two elements per lane in registers took 207 (7.16 -> 7.01 ms per 1M walks).
-    constexpr int PASSES = ((int)C::B + tbl_words((int)CAP)) / tbl_words((int)CAP);   // the table holds the stage's slots 0 .. B in one piece, or a half / a third of them
-    static_assert(((int)C::B + PASSES) / PASSES <= tbl_words((int)CAP), "a pass of the final stage must fit the tier's bucket table");
-#define UGS_FINAL_LDS(LO, HI, NJ) UGS_FINAL_CASE(LO, HI, (stage_final<GS, NJ, PASSES>(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel)))
-    if constexpr (GS == 64) {
-        UGS_FINAL_CASE(1, 1, stage_final_reg(ws, g, OLD, C::NOLD, c, C::B, C::M, C::S, rsel))
-        UGS_FINAL_LDS(2, 2, 2) UGS_FINAL_LDS(3, 3, 3) UGS_FINAL_LDS(4, 4, 4) UGS_FINAL_LDS(5, 5, 5) UGS_FINAL_LDS(6, 6, 6) UGS_FINAL_LDS(7, 7, 7)
-    } else {
-        UGS_FINAL_LDS(1, 1, 1) UGS_FINAL_LDS(2, 3, 3) UGS_FINAL_LDS(4, 5, 5) UGS_FINAL_LDS(6, 7, 7)
-    }
-    UGS_FINAL_LDS(8, 9, 9) UGS_FINAL_LDS(10, 11, 11) UGS_FINAL_LDS(12, 13, 13) UGS_FINAL_LDS(14, 17, 17) UGS_FINAL_LDS(18, 22, 22) UGS_FINAL_LDS(23, 1 << 20, 33)
-#undef UGS_FINAL_LDS
-#undef UGS_FINAL_CASE
-    return Pick{0u, 0u};
+    return final_tree<GS, MAXPER, STAGE, var_first_with_hi_at_least<GS>(pmin), var_first_with_hi_at_least<GS>(pmax)>(ws, g, per, c, rsel);
 }
 
 // the stages to compute come as a bit set: one scalar bit test and branch per stage
@@ -843,7 +891,11 @@ template <int NST> __device__ __forceinline__ uint32_t chain_lane_const(int lane
     return v;
 }
 __device__ __forceinline__ int chain_index_below_lanes(uint32_t x, uint32_t chain_lane) {
-    return (int)__popcll(__ballot(chain_lane < x));
+    int n = (int)__popcll(__ballot(chain_lane < x));
+    // opaque 32-bit value: the compiler otherwise compares the 64-bit population count itself, and an ordered 64-bit compare of
+    // scalars has no scalar instruction (v_cmp_lt_u64 + s_and + s_cbranch_vccz per test of the stage dispatch)
+    asm volatile("" : "+s"(n));
+    return n;
 }
 template <int NST> __device__ __forceinline__ int chain_index_below(uint32_t x) {     // number of the first NST chain values < x
     // x <= 2^16: the sign bit of B[i] - x says x > B[i] -- two scalar instructions per term and no condition codes (the
@@ -894,6 +946,7 @@ struct StageCtx {
     uint4 *EL;               // [UGS_STAGE_ENTRIES]: x = CSR position, y = the member the entry points to, z = scanned vertex's local index
     uint32_t ne;             // hits so far (may exceed the list: the row then goes to the row-reading fill kernel)
     bool on;
+    uint64_t onm;            // all ones when staging is on: `hits & onm` tests "on, and any hit" with one scalar AND
 };
 
 template <int GS>
@@ -905,18 +958,34 @@ __device__ __forceinline__ void stage_hits(StageCtx &sc, const Grp<GS> &g, bool 
     sc.ne += (uint32_t)__popcll(im);
 }
 
+// The same with the hits' lane mask taken by the caller in the block that computes the compare (one walk per wave).  A ballot asked
+// for in a LATER block than its compare is rebuilt by the compiler from a 0/1 vector (v_cndmask + v_cmp_ne and a wait-state filler
+// between them); a mask taken on the spot is the compare's own result, stays in scalar registers, and comes back as a lane
+// predicate for free (inverse ballot: the mask goes straight into EXEC).
+__device__ __forceinline__ void stage_hits_mask(StageCtx &sc, const Grp<64> &g, uint64_t im, uint32_t w, uint32_t p, uint32_t size) {
+    im &= sc.onm;
+    if (!im) return;
+    const uint32_t slot = sc.ne + g.below(im);
+    if (__builtin_amdgcn_inverse_ballot_w64(im) && slot < UGS_STAGE_ENTRIES) sc.EL[slot] = make_uint4(p, w, size - 1u, 0u);
+    sc.ne += (uint32_t)__popcll(im);
+}
+
 // The probe loops of the membership table for the one-walk-per-wave LDS tiers, written against the EXEC mask directly.  Every
 // active lane probes its own key; a lane is done when it meets an empty slot (and, inserting, has taken it) or its key.  The
 // compiler's version of this loop -- unrolled eight times, one saved EXEC mask per level and two scalar instructions per level on
 // the way out -- spends ~6 scalar instructions per probe; here the two `v_cmpx` narrow EXEC to the lanes still probing, the loop
 // ends when EXEC is empty and the entry mask is restored once.  No scalar ALU instruction inside the loop.
 // The table is never full (scan_chunk's hlimit guard), and the probe step is odd, so every lane terminates.
-__device__ __forceinline__ uint32_t probe_insert_lds(uint32_t *HK, uint32_t hmask, uint32_t slot, uint32_t step, uint32_t w, uint32_t &seen) {
+// The loops start by narrowing EXEC to the CANDIDATES (entries whose rank passes the suffix filter: one v_cmpx) -- an `if (cand)` around
+// the asm made the compiler build an if/else of saved masks (five scalar instructions and two duplicated vector ones per chunk).
+__device__ __forceinline__ uint32_t probe_insert_lds(uint32_t *HK, uint32_t hmask, uint32_t slot, uint32_t step, uint32_t w, uint32_t &seen,
+                                                     int rank, uint32_t root_vi) {
     const uint32_t base = (uint32_t)(uintptr_t)HK;                            // low half of a flat LDS pointer = its LDS address
     uint32_t addr = base + (slot << 2), t;
     uint64_t saved;
     asm volatile(
         "s_mov_b64 %[sv], exec\n"
+        "v_cmpx_le_i32 %[rv], %[rk]\n"
         "ugs_pi_%=:\n"
         "ds_cmpst_rtn_b32 %[seen], %[addr], %[empty], %[neww]\n"
         "s_waitcnt lgkmcnt(0)\n"
@@ -931,16 +1000,18 @@ __device__ __forceinline__ uint32_t probe_insert_lds(uint32_t *HK, uint32_t hmas
         "ugs_pd_%=:\n"
         "s_mov_b64 exec, %[sv]\n"
         : [seen] "+v"(seen), [slot] "+v"(slot), [addr] "+v"(addr), [t] "=&v"(t), [sv] "=&s"(saved)
-        : [empty] "v"(kEmpty), [neww] "v"(w | kFresh), [w] "v"(w), [step] "v"(step), [hmask] "s"(hmask), [base] "s"(base)
+        : [empty] "v"(kEmpty), [neww] "v"(w | kFresh), [w] "v"(w), [step] "v"(step), [hmask] "s"(hmask), [base] "s"(base), [rk] "v"(rank), [rv] "s"(root_vi)
         : "vcc", "memory");
     return slot;
 }
-__device__ __forceinline__ void probe_find_lds(const uint32_t *HK, uint32_t hmask, uint32_t slot, uint32_t step, uint32_t w, uint32_t &seen) {
+__device__ __forceinline__ void probe_find_lds(const uint32_t *HK, uint32_t hmask, uint32_t slot, uint32_t step, uint32_t w, uint32_t &seen,
+                                               int rank, uint32_t root_vi) {
     const uint32_t base = (uint32_t)(uintptr_t)HK;
     uint32_t addr = base + (slot << 2), t;
     uint64_t saved;
     asm volatile(
         "s_mov_b64 %[sv], exec\n"
+        "v_cmpx_le_i32 %[rv], %[rk]\n"
         "ugs_pf_%=:\n"
         "ds_read_b32 %[seen], %[addr]\n"
         "s_waitcnt lgkmcnt(0)\n"
@@ -955,13 +1026,14 @@ __device__ __forceinline__ void probe_find_lds(const uint32_t *HK, uint32_t hmas
         "ugs_pe_%=:\n"
         "s_mov_b64 exec, %[sv]\n"
         : [seen] "+v"(seen), [slot] "+v"(slot), [addr] "+v"(addr), [t] "=&v"(t), [sv] "=&s"(saved)
-        : [w] "v"(w), [step] "v"(step), [hmask] "s"(hmask), [base] "s"(base)
+        : [w] "v"(w), [step] "v"(step), [hmask] "s"(hmask), [base] "s"(base), [rk] "v"(rank), [rv] "s"(root_vi)
         : "vcc", "memory");
 }
 
 // One chunk of an adjacency row: lane holds entry e (neighbour, rank) at CSR position p (a plan has < 2^31 entries); lanes
 // without an entry hold kNoEntry, whose rank -1 fails the suffix filter, so `cand` is one signed compare (ranks are < 2^30).
-#define UGS_NO_ENTRY make_int2(0, -1)
+// (their vertex number, all ones, equals no vertex: a test `w == some candidate` needs no `cand &&` in front)
+#define UGS_NO_ENTRY make_int2(-1, -1)
 // GUARD = false: the caller has checked that the whole row fits (candidates and table entries), so the per-chunk tests are left out.
 template <int GS, class SP, bool ADD, bool STG, bool GUARD = true>
 __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g, uint32_t v, uint32_t root_vi, uint32_t size, uint32_t &c,
@@ -971,14 +1043,51 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
     uint32_t slot = hash_slot(w, ws.hmask);
     const uint32_t step = hash_step(w);
     bool in_s = false;
+    if constexpr (GS == 64 && sizeof(typename SP::TW) == 4) {
+        // One walk per wave, LDS workspace: every lane predicate is taken as a lane MASK in the block that computes it and carried
+        // in scalar registers (see stage_hits_mask); the probes narrow EXEC to the candidates themselves.
+        if (ADD) {
+            if constexpr (GUARD) { if (hcount + (uint32_t)__popcll(__ballot(cand)) > ws.hlimit) return false; }
+            uint32_t seen = kKeyMask;                             // what a lane that is no candidate keeps: not empty, equal to no vertex
+            STAMP_SUB_BEGIN();
+            slot = probe_insert_lds(ws.HK, ws.hmask, slot, step, w, seen, e.y, root_vi);
+            STAMP_SUB_END_OF(1, 6);
+            const uint64_t insm = __ballot(seen == kEmpty);                                     // inserted by this lane
+            const uint64_t im = __ballot((seen & (kKeyMask | kInS)) == (w | kInS));             // found, and a member of the sample
+            uint64_t dupm = __ballot((seen & (kKeyMask | kFresh)) == (w | kFresh));             // found, and inserted by this very chunk
+            SP::sync();
+            // first occurrences (see below): the inserting lanes, except that a vertex repeated inside the chunk is represented by
+            // the LOWEST lane holding it
+            uint64_t fm = insm;
+            while (dupm) {
+                const uint32_t wi = g.bcast(w, __builtin_ctzll(dupm));
+                const uint64_t grp = __ballot(w == wi);           // (a vertex has one rank: its lanes are candidates all or none)
+                fm = (fm & ~grp) | (grp & (0ull - grp));
+                dupm &= ~grp;
+            }
+            if (__builtin_amdgcn_inverse_ballot_w64(insm)) ws.HK[slot] = w;                      // the chunk is over for this key: drop kFresh
+            ecount += __builtin_amdgcn_inverse_ballot_w64(im) ? (w == v ? 1u : 2u) : 0u;         // per lane, summed over the wave at the end of the walk
+            if constexpr (STG) stage_hits_mask(sc, g, im, w, p, size);
+            const uint32_t nnew = (uint32_t)__popcll(fm);
+            if constexpr (GUARD) { if (c + nnew > ws.cap) return false; }
+            if (__builtin_amdgcn_inverse_ballot_w64(fm)) ws.D[c + g.below(fm)] = w;
+            c += nnew;
+            hcount += nnew;
+            SP::sync();
+        } else {
+            uint32_t seen = kEmpty;
+            probe_find_lds(ws.HK, ws.hmask, slot, step, w, seen, e.y, root_vi);
+            const uint64_t im = __ballot((seen & (kKeyMask | kInS)) == (w | kInS));             // kEmpty (no candidate, or not seen) matches no vertex
+            ecount += __builtin_amdgcn_inverse_ballot_w64(im) ? (w == v ? 1u : 2u) : 0u;
+            if constexpr (STG) stage_hits_mask(sc, g, im, w, p, size);
+        }
+        return true;
+    } else
     if (ADD) {
         if constexpr (GUARD) { if (hcount + (uint32_t)__popcll(g.ballot(cand)) > ws.hlimit) return false; }
         // probe: only `seen` and `slot` are carried round the loop; what happened is read off `seen` afterwards
         uint32_t seen = kKeyMask;                                 // a value no probe returns for a candidate
         STAMP_SUB_BEGIN();
-        if constexpr (GS == 64 && sizeof(typename SP::TW) == 4) {
-            if (cand) slot = probe_insert_lds(ws.HK, ws.hmask, slot, step, w, seen);
-        } else
         if (cand) {
             for (uint32_t it = 0; it <= ws.hmask; ++it) {         // the table is never full
                 seen = atomicCAS(&ws.HK[slot], kEmpty, w | kFresh);
@@ -1024,9 +1133,6 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
         SP::sync();
     } else {
         uint32_t seen = kEmpty;
-        if constexpr (GS == 64 && sizeof(typename SP::TW) == 4) {
-            if (cand) probe_find_lds(ws.HK, ws.hmask, slot, step, w, seen);
-        } else
         if (cand) {
             for (uint32_t it = 0; it <= ws.hmask; ++it) {
                 seen = ws.HK[slot];
@@ -1088,8 +1194,13 @@ __device__ __forceinline__ bool scan_prow(const Work<SP> &ws, const Grp<64> &g, 
     if ((uint32_t)(g.lane - 1) >= n0) e0 = UGS_NO_ENTRY;                        // the header's lane and the lanes behind the row
     // a row whose every entry could be a new candidate and still fit needs no per-chunk overflow tests (nearly all rows); the
     // others take the guarded chunks, so the walks a tier hands on are exactly those it handed on before
+    // (`n0 != 0` is tested on an opaque scalar copy in each path: shared between the two, the compiler carries the condition through
+    // a vector register -- v_cndmask, v_cmp_ne, s_and, s_cbranch_vccnz)
+    uint32_t n0a = n0, n0b = n0;
+    asm volatile("" : "+s"(n0a));
+    asm volatile("" : "+s"(n0b));
     if (ADD && hcount + deg <= ws.hlimit && c + deg <= ws.cap) {
-        if (n0) scan_chunk<64, SP, ADD, STG, false>(ws, g, v, root_vi, size, c, hcount, ecount, sc, e0, start + (uint32_t)g.lane - 1u);
+        if (n0a) scan_chunk<64, SP, ADD, STG, false>(ws, g, v, root_vi, size, c, hcount, ecount, sc, e0, start + (uint32_t)g.lane - 1u);
         const uint32_t r1 = start + deg;
         for (uint32_t base = start + inl; base < r1; base += 64) {
             const uint32_t p = base + (uint32_t)g.lane;
@@ -1099,7 +1210,7 @@ __device__ __forceinline__ bool scan_prow(const Work<SP> &ws, const Grp<64> &g, 
         }
         return true;
     }
-    if (n0 && !scan_chunk<64, SP, ADD, STG>(ws, g, v, root_vi, size, c, hcount, ecount, sc, e0, start + (uint32_t)g.lane - 1u)) return false;
+    if (n0b && !scan_chunk<64, SP, ADD, STG>(ws, g, v, root_vi, size, c, hcount, ecount, sc, e0, start + (uint32_t)g.lane - 1u)) return false;
     const uint32_t r1 = start + deg;
     for (uint32_t base = start + inl; base < r1; base += 64) {
         const uint32_t p = base + (uint32_t)g.lane;
@@ -1174,7 +1285,12 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
     const Grp<GS> &g = g_;
     constexpr bool STG = GS == 64 && sizeof(typename SP::TW) == 4;             // one walk per wave, LDS workspace
     StageCtx sc;
-    sc.EL = EL; sc.ne = 0u; sc.on = STG && a.stage != nullptr && EL != nullptr;
+    sc.EL = EL; sc.ne = 0u; sc.on = STG && a.stage != nullptr && EL != nullptr; sc.onm = 0ull;
+    if constexpr (STG) {      // (opaque, or the compiler turns `hits & onm` back into two tests)
+        uint32_t on32 = g.uni(sc.on ? 1u : 0u);
+        asm volatile("" : "+s"(on32));
+        sc.onm = 0ull - (uint64_t)on32;
+    }
     const UgsPlanDev &P = a.plan;
     const int64_t row = a.row_begin + row_rel;
     int64_t gi, i;
@@ -1311,8 +1427,15 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
 #pragma unroll
                 for (int u = 0; u < 4; ++u) x[u] = ws.D[t0 + u * GS + g.lane + 1];
                 SP::sync();
+                {   // (the clamp against cap-1-u*GS on the un-offset index: u*GS rides in the write's offset field, one v_min per write)
+                    const uint32_t tb = t0 + (uint32_t)g.lane;
+                    constexpr uint32_t last = (uint32_t)(MAXPER * GS) - 1u;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const uint32_t t = t0 + u * GS + g.lane; ws.D[t < ws.cap - 1u ? t : ws.cap - 1u] = x[u]; }
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t lim4 = (last - (uint32_t)(u * GS)) * 4u, tb4 = tb * 4u;                      // byte offsets: no shift after the clamp
+                        *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(ws.D + u * GS) + (tb4 < lim4 ? tb4 : lim4)) = x[u];
+                    }
+                }
             } else {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { const uint32_t t = t0 + u * GS + g.lane; x[u] = (t + 1 < c) ? ws.D[t + 1] : 0u; }
@@ -1337,15 +1460,46 @@ __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, c
         STAMP_END(8);
         {   // w is now a member of the sample: flag its hash entry (the group probes GS consecutive slots per round trip)
             const uint32_t step = hash_step(w);
-            uint32_t s = (hash_slot(w, ws.hmask) + (uint32_t)g.lane * step) & ws.hmask;
             // lane i looks at the i-th slot of w's probe sequence; the entry is there (w was a candidate) and almost always among
-            // the first GS slots, so the loop is written around that case: read, compare, one scalar test, write
+            // the first GS slots
+            if constexpr (GS == 64 && sizeof(typename SP::TW) == 4) {
+                // one walk per wave: the first round against EXEC -- read, v_cmpx (the lane that sees the entry stays), write under that
+                // mask (nobody writes when nobody saw it), and the mask itself says whether a second round is needed: seven
+                // instructions and no taken branch where the compiler's loop took sixteen and two
+                uint32_t ls;                                           // lane * step (< 2^18): the full-rate 24-bit multiply, by hand -- the
+                asm("v_mul_u32_u24 %0, %1, %2" : "=v"(ls) : "s"(step), "v"(g.lane));   // lane index is opaque to the compiler (do_walk), which then takes v_mul_lo_u32
+                uint32_t s = (hash_slot(w, ws.hmask) + ls) & ws.hmask;
+                const uint32_t addr = (uint32_t)(uintptr_t)ws.HK + (s << 2);
+                uint32_t t;
+                uint64_t saved, found;
+                asm volatile(
+                    "s_mov_b64 %[sv], exec\n"
+                    "ds_read_b32 %[t], %[addr]\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_cmpx_eq_u32 %[w], %[t]\n"
+                    "ds_write_b32 %[addr], %[wf]\n"
+                    "s_mov_b64 %[fd], exec\n"
+                    "s_mov_b64 exec, %[sv]\n"
+                    : [t] "=&v"(t), [sv] "=&s"(saved), [fd] "=&s"(found)
+                    : [addr] "v"(addr), [w] "s"(w), [wf] "v"(w | kInS)
+                    : "vcc", "memory");
+                if (__builtin_expect(found == 0ull, 0)) {             // deeper than 64 probes: the general loop
+                    bool hit = false;
+                    for (uint32_t it = GS; !g.any(hit) && it <= ws.hmask; it += GS) {
+                        s = (s + GS * step) & ws.hmask;
+                        hit = ws.HK[s] == w;
+                    }
+                    if (hit) ws.HK[s] = w | kInS;
+                }
+            } else {
+            uint32_t s = (hash_slot(w, ws.hmask) + (uint32_t)g.lane * step) & ws.hmask;
             bool hit = ws.HK[s] == w;                                 // a candidate's entry carries no flag
             for (uint32_t it = GS; __builtin_expect(!g.any(hit), 0) && it <= ws.hmask; it += GS) {
                 s = (s + GS * step) & ws.hmask;
                 hit = ws.HK[s] == w;
             }
             if (hit) ws.HK[s] = w | kInS;
+            }
             if constexpr (GS == 64) SV[size] = w;                     // every lane, same word, same value: no lane-0 mask to set up
             else
             if (g.lane == 0) SV[size] = w;

@@ -42,7 +42,7 @@ template <int STAGE, int NJ, bool REG = true> __global__ __launch_bounds__(64, 5
 }
 template <bool ADD> __global__ __launch_bounds__(64, 5) void probe_chunk(uint32_t *out, const uint32_t *in, uint32_t c, uint32_t rsel, const int2 *adj, uint2 *stage) {
     PROBE_PRE
-    StageCtx sc; sc.EL = pw.EL; sc.ne = rsel & 3; sc.on = stage != nullptr;
+    StageCtx sc; sc.EL = pw.EL; sc.ne = rsel & 3; sc.on = stage != nullptr; { uint32_t on32 = (uint32_t)__builtin_amdgcn_readfirstlane(sc.on ? 1 : 0); asm volatile("" : "+s"(on32)); sc.onm = 0ull - (uint64_t)on32; }
     uint32_t hcount = c + 3, ecount = rsel >> 8, cc = c;
     int2 e = UGS_NO_ENTRY; if (threadIdx.x < 40) e = adj[threadIdx.x];
     const bool ok = scan_chunk<64, LdsSpace, ADD, true>(pw.ws, g, rsel, c >> 3, 3, cc, hcount, ecount, sc, e, threadIdx.x + 1000u);
