@@ -65,7 +65,7 @@ struct UgsWalkArgs {
     int32_t m;               // samples per graph
     int32_t k;
     int32_t mode;            // UGS_MODE_* / UGS_EDGE_* (0 local, 1 flat, 2 global)
-    int32_t pad;             // UGS_SMALL_CAP: first-tier launch of tier S in its 32-candidate form
+    int32_t pad;             // UGS_SMALL_CAP: first-tier launch of tier S in its 32-candidate form; UGS_WIDE_LANES: tier S with 16 lanes per walk
     int64_t extra_node_off;  // handle API "global": base_offset
     uint64_t seed64;         // (uint64_t)(int64_t)seed
     const uint64_t *seed_ptr;// if not NULL the seed is read from here (captured HIP graphs: the value changes between replays)
@@ -138,6 +138,9 @@ static constexpr int UGS_TIER_LANES[UGS_LDS_TIERS] = {8, 64, 64, 64, 64, 64};   
 static constexpr int UGS_TIER_HASH_LIMIT[UGS_LDS_TIERS] = {96, 448, 896, 1536, 1792, 3072};  // TierCfg<CAP>::HLIMIT (static_assert in ugs_kernels.hip)
 // a form of tier S with half the workspace, for plans whose walks cannot hold more than 32 candidates (UgsWalkArgs::pad = UGS_SMALL_CAP)
 #define UGS_SMALL_CAP 32
+// tier S with 16 lanes per walk instead of 8 (UgsWalkArgs::pad = UGS_WIDE_LANES): first-tier launches whose walks are all resident at
+// once (row_count <= CUs x blocks per CU x 16) of plans whose walks cannot be handed on -- such a launch lasts as long as one walk
+#define UGS_WIDE_LANES 16
 #define UGS_SMALL_HASH_LIMIT 48
 
 hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int device_cus, int share_percent, hipStream_t s, UgsLaunchInfo *info);

@@ -486,7 +486,7 @@ void pool_put(PoolBuf &b) {
 // plans
 // ---------------------------------------------------------------------------------------------------------------
 struct TierChoice { int first = UGS_TIER_S; int second = -1 /* LDS tier that redoes the rows the first one hands on */; bool third_G = false; int64_t bound = 0;
-                    bool small = false /* tier S in its 32-candidate form */; };
+                    bool small = false /* tier S in its 32-candidate form */; bool wide = false /* tier S may run with 16 lanes per walk */; };
 
 struct ugs_plan {
     int device = -1, cus = 256;
@@ -931,6 +931,9 @@ TierChoice choose_tier(ugs_plan *p, int k) {
     // 8 lanes of a chunk), so that it needs no hand-on chain of its own
     t.small = t.first == UGS_TIER_S && bound <= UGS_SMALL_CAP && bound + 1 + UGS_TIER_LANES[UGS_TIER_S] <= UGS_SMALL_HASH_LIMIT &&
               std::getenv("UGS_NO_SMALL_TIER") == nullptr;
+    // tier S with 16 lanes per walk (UGS_WIDE_LANES; plan_walk_impl takes it for launches that fit the GPU at once): only where no walk
+    // can be handed on with 16-lane chunks either
+    t.wide = t.first == UGS_TIER_S && !t.small && bound <= UGS_TIER_CAP[UGS_TIER_S] && bound + 1 + UGS_WIDE_LANES <= UGS_TIER_HASH_LIMIT[UGS_TIER_S];
     p->tiers[k] = t;
     return t;
 }
@@ -1841,6 +1844,7 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
     }
     a.work_next = dyn ? static_cast<unsigned long long *>(plan->work.p) + 0 : nullptr;
     if (tc.small) a.pad = UGS_SMALL_CAP;
+    else if (tc.wide && !dyn && std::getenv("UGS_NO_WIDE_TIER") == nullptr /* read per call: tests and A/Bs toggle it */ && row_count <= (int64_t)plan->cus * 3 /* blocks per CU, UGS_BLOCKS_S */ * UGS_WIDE_LANES) a.pad = UGS_WIDE_LANES;
     // ugs_plan_step: the fill kernel can turn the counts into edge_ptr itself when the walk leaves the sums of 8 rows beside them --
     // 8-lane tier, rows taken by index (static split), no walk handed on, no capture in progress, a row count the fill's blocks can
     // add up in a few dozen loads per thread

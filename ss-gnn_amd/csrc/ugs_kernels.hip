@@ -1615,21 +1615,34 @@ __global__ __launch_bounds__(BLOCK, CAP <= 32 ? 4 : ((CAP > 64 && CAP <= 512) ? 
         }
         return;
     }
-    if constexpr (GS == 8) {
+    if constexpr (GS == 8 || GS == 16) {
         if (a.wsum) {
             // Small-batch step (ugs_plan_step): beside the per-row counts the walk leaves the SUM of every 8 consecutive rows -- the
-            // 8 groups of a wave hold 8 consecutive rows and come back from their walks together -- so that the fill kernel can add
+            // groups of a wave hold consecutive rows and come back from their walks together -- so that the fill kernel can add
             // up what lies in front of a tile from plain, cacheable words written by the kernel BEFORE it (no communication between
             // the fill's blocks: that cost 15 us on the QM9-shaped batch, see ugs_fill_scan).  Rows are taken by index here (no
             // list of handed-on rows: the host asks for the sums only when no walk can be handed on).
+            constexpr int RPW = 64 / GS;                                     // rows per wave: 8, or 4 (two waves make a sum)
+            __shared__ uint32_t wave_sum[BLOCK / 64];
             for (int64_t it0 = (int64_t)blockIdx.x * GROUPS; it0 < total; it0 += ngroups) {
                 const int64_t it = it0 + gib;
                 uint32_t ne = 0u;
                 if (it < total) (void)do_walk<GS, LdsSpace, (CAP + GS - 1) / GS, PAD>(ws, g, a, it, SV, EL, &ne);
                 uint32_t sum = g.lane == 0 ? ne : 0u;
-                sum += __shfl_xor(sum, 8, 64); sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
-                const int64_t w0 = it0 + (int64_t)((threadIdx.x >> 6) * 8);          // first row of this wave
-                if ((threadIdx.x & 63) == 0 && w0 < total) a.wsum[w0 >> 3] = sum;
+#pragma unroll
+                for (int d = GS; d < 64; d <<= 1) sum += __shfl_xor(sum, d, 64);
+                if constexpr (RPW == 8) {
+                    const int64_t w0 = it0 + (int64_t)((threadIdx.x >> 6) * 8);      // first row of this wave
+                    if ((threadIdx.x & 63) == 0 && w0 < total) a.wsum[w0 >> 3] = sum;
+                } else {
+                    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = sum;
+                    __syncthreads();
+                    if (threadIdx.x < GROUPS / 8) {
+                        const int64_t r0 = it0 + (int64_t)threadIdx.x * 8;           // (it0 is a multiple of the block's 16 rows)
+                        if (r0 < total) a.wsum[r0 >> 3] = wave_sum[2 * threadIdx.x] + wave_sum[2 * threadIdx.x + 1];
+                    }
+                    __syncthreads();
+                }
             }
             return;
         }
@@ -2081,6 +2094,10 @@ hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, int share_pe
         // graphs of at most 33 vertices (QM9-, MUTAG-sized): 32 candidates per walk, 27 KB of LDS and 95 VGPRs per block -- five blocks
         // per CU instead of three (the QM9-shaped batch of 65 536 rows takes two trips instead of three)
         if (a.pad == UGS_SMALL_CAP && !a.in_list) return launch_lds<8, UGS_SMALL_CAP, 256>(a, cus, part(5), s, info, "ugs_walk_lds<8,32>");
+        // 16 lanes per walk where the host asks for them: a batch whose walks are all resident at once is bound by ONE walk's
+        // latency -- four walks per wave diverge less than eight and a stage has half the elements per lane (PROTEINS-shaped batch of
+        // 8192 rows: 26.7 -> 23.1 us; 32 lanes: 30.0)
+        if (a.pad == UGS_WIDE_LANES && !a.in_list) return launch_lds<UGS_WIDE_LANES, 64, 256>(a, cus, part(UGS_BLOCKS_S), s, info, "ugs_walk_lds<16,64>");
         return launch_lds<8, 64, 256>(a, cus, part(UGS_BLOCKS_S), s, info, "ugs_walk_lds<8,64>");
     // one walk per wave: two walks per wave (GS 32) measured 26.4 ms vs 18.7 ms per 1M walks on C5 (two chunks per row)
     // resident one-wave blocks per CU: LDS is granted in 1280-byte granules (128 per CU) -- 7648 B = 6 granules -> 21 blocks, of
