@@ -716,12 +716,17 @@ __device__ __forceinline__ Pick stage_final(const Work<LdsSpace> &ws, const Grp<
     // (no boolean is carried from slot to slot: an OR of lane predicates is a scalar instruction per slot -- the offset's sentinel
     // says afterwards whether the lane holds the bucket)
     uint32_t hb = 0u, ho = 0xFFFFFFFFu;
+    {   // all compares first, then the selects: a v_cndmask right behind the v_cmp whose mask it reads costs a two-wait-state filler
+        uint32_t e[NJ];
+        bool h[NJ];
 #pragma unroll
-    for (int j = NJ - 1; j >= 0; --j) {
-        run += gs[j];
-        const uint32_t e = run - target1;                                 // one unsigned compare: run - size <= target < run; e = members of the bucket BELOW the answer
-        const bool h = e < gs[j];
-        hb = h ? bk[j] : hb; ho = h ? e : ho;
+        for (int j = NJ - 1; j >= 0; --j) {
+            run += gs[j];
+            e[j] = run - target1;                                         // one unsigned compare: run - size <= target < run; e = members of the bucket BELOW the answer
+            h[j] = e[j] < gs[j];
+        }
+#pragma unroll
+        for (int j = NJ - 1; j >= 0; --j) { hb = h[j] ? bk[j] : hb; ho = h[j] ? e[j] : ho; }
     }
     const uint64_t hm = g.ballot(ho != 0xFFFFFFFFu);
     // (a bucket holds the target rank and a member of it the offset: the masks are never empty; unguarded, the lane number is the
@@ -748,11 +753,16 @@ __device__ __forceinline__ Pick stage_final(const Work<LdsSpace> &ws, const Grp<
         below = g.prefix_incl(own) - own;
     }
     uint32_t mine = 0xFFFFFFFFu;
+    {
+        bool hit[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const uint32_t bl = cj[j] != 0u ? below : 0xFFFFFFFFu;           // a member of the bucket with exactly `off` members below it
-        mine = bl == off ? pos[j] : mine;
-        below += cj[j];
+        for (int j = 0; j < NJ; ++j) {
+            const uint32_t bl = cj[j] != 0u ? below : 0xFFFFFFFFu;       // a member of the bucket with exactly `off` members below it
+            hit[j] = bl == off;
+            below += cj[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) mine = hit[j] ? pos[j] : mine;
     }
     const uint64_t mk = g.ballot(mine != 0xFFFFFFFFu);
     const int src = GS == 64 ? __builtin_ctzll(mk) : (mk ? (__ffsll((long long)mk) - 1) : 0);
