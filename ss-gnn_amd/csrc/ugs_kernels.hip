@@ -1040,6 +1040,61 @@ __device__ __forceinline__ void probe_find_lds(const uint32_t *HK, uint32_t hmas
         : "vcc", "memory");
 }
 
+// The same loops for the tiers with several walks per wave (8 or 16 lanes per walk): the table's address and the root's rank differ
+// between the wave's groups, so they come in vector registers.  (The compiler's versions of these divergent loops -- a compare-and-swap
+// with two exits -- rebuild the EXEC mask with a dozen scalar instructions per trip.)
+__device__ __forceinline__ uint32_t probe_insert_lds_v(uint32_t *HK, uint32_t hmask, uint32_t slot, uint32_t step, uint32_t w, uint32_t &seen,
+                                                       int rank, uint32_t root_vi) {
+    const uint32_t base = (uint32_t)(uintptr_t)HK;
+    uint32_t addr = base + (slot << 2), t;
+    uint64_t saved;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n"
+        "v_cmpx_le_i32 %[rv], %[rk]\n"
+        "ugs_qi_%=:\n"
+        "ds_cmpst_rtn_b32 %[seen], %[addr], %[empty], %[neww]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_and_b32 %[t], 0x3fffffff, %[seen]\n"
+        "v_cmpx_ne_u32 -1, %[seen]\n"
+        "v_cmpx_ne_u32 %[t], %[w]\n"
+        "s_cbranch_execz ugs_qd_%=\n"
+        "v_add_u32 %[slot], %[slot], %[step]\n"
+        "v_and_b32 %[slot], %[hmask], %[slot]\n"
+        "v_lshl_add_u32 %[addr], %[slot], 2, %[base]\n"
+        "s_branch ugs_qi_%=\n"
+        "ugs_qd_%=:\n"
+        "s_mov_b64 exec, %[sv]\n"
+        : [seen] "+v"(seen), [slot] "+v"(slot), [addr] "+v"(addr), [t] "=&v"(t), [sv] "=&s"(saved)
+        : [empty] "v"(kEmpty), [neww] "v"(w | kFresh), [w] "v"(w), [step] "v"(step), [hmask] "s"(hmask), [base] "v"(base), [rk] "v"(rank), [rv] "v"(root_vi)
+        : "vcc", "memory");
+    return slot;
+}
+__device__ __forceinline__ void probe_find_lds_v(const uint32_t *HK, uint32_t hmask, uint32_t slot, uint32_t step, uint32_t w, uint32_t &seen,
+                                                 int rank, uint32_t root_vi) {
+    const uint32_t base = (uint32_t)(uintptr_t)HK;
+    uint32_t addr = base + (slot << 2), t;
+    uint64_t saved;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n"
+        "v_cmpx_le_i32 %[rv], %[rk]\n"
+        "ugs_qf_%=:\n"
+        "ds_read_b32 %[seen], %[addr]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_and_b32 %[t], 0x3fffffff, %[seen]\n"
+        "v_cmpx_ne_u32 -1, %[seen]\n"
+        "v_cmpx_ne_u32 %[t], %[w]\n"
+        "s_cbranch_execz ugs_qe_%=\n"
+        "v_add_u32 %[slot], %[slot], %[step]\n"
+        "v_and_b32 %[slot], %[hmask], %[slot]\n"
+        "v_lshl_add_u32 %[addr], %[slot], 2, %[base]\n"
+        "s_branch ugs_qf_%=\n"
+        "ugs_qe_%=:\n"
+        "s_mov_b64 exec, %[sv]\n"
+        : [seen] "+v"(seen), [slot] "+v"(slot), [addr] "+v"(addr), [t] "=&v"(t), [sv] "=&s"(saved)
+        : [w] "v"(w), [step] "v"(step), [hmask] "s"(hmask), [base] "v"(base), [rk] "v"(rank), [rv] "v"(root_vi)
+        : "vcc", "memory");
+}
+
 // One chunk of an adjacency row: lane holds entry e (neighbour, rank) at CSR position p (a plan has < 2^31 entries); lanes
 // without an entry hold kNoEntry, whose rank -1 fails the suffix filter, so `cand` is one signed compare (ranks are < 2^30).
 // (their vertex number, all ones, equals no vertex: a test `w == some candidate` needs no `cand &&` in front)
@@ -1098,6 +1153,9 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
         // probe: only `seen` and `slot` are carried round the loop; what happened is read off `seen` afterwards
         uint32_t seen = kKeyMask;                                 // a value no probe returns for a candidate
         STAMP_SUB_BEGIN();
+        if constexpr (sizeof(typename SP::TW) == 4) {
+            slot = probe_insert_lds_v(reinterpret_cast<uint32_t *>(ws.HK), ws.hmask, slot, step, w, seen, e.y, root_vi);
+        } else
         if (cand) {
             for (uint32_t it = 0; it <= ws.hmask; ++it) {         // the table is never full
                 seen = atomicCAS(&ws.HK[slot], kEmpty, w | kFresh);
@@ -1143,6 +1201,9 @@ __device__ __forceinline__ bool scan_chunk(const Work<SP> &ws, const Grp<GS> &g,
         SP::sync();
     } else {
         uint32_t seen = kEmpty;
+        if constexpr (sizeof(typename SP::TW) == 4) {
+            probe_find_lds_v(reinterpret_cast<const uint32_t *>(ws.HK), ws.hmask, slot, step, w, seen, e.y, root_vi);
+        } else
         if (cand) {
             for (uint32_t it = 0; it <= ws.hmask; ++it) {
                 seen = ws.HK[slot];
@@ -1291,6 +1352,7 @@ template <int GS, class SP, int MAXPER, bool PAD>
 __device__ __forceinline__ bool do_walk(const Work<SP> &ws, const Grp<GS> &g_, const UgsWalkArgs &a, int64_t row_rel,
                                         uint32_t *SV /* [UGS_KMAX] group-private */, uint4 *EL /* [UGS_STAGE_ENTRIES] or null */,
                                         uint32_t *nedges_out = nullptr /* the row's edge-entry count (0 if the walk is handed on) */) {
+
     static_assert(!PAD || GS == 64, "padded rows are read by a whole wave");
     const Grp<GS> &g = g_;
     constexpr bool STG = GS == 64 && sizeof(typename SP::TW) == 4;             // one walk per wave, LDS workspace
@@ -2075,7 +2137,7 @@ uint32_t ugs_chain_at_least(int64_t c, int *index_out) {   // smallest chain val
 
 template <int GS, int CAP, int BLOCK>
 static hipError_t launch_lds(const UgsWalkArgs &a, int cus, int blocks_per_cu, hipStream_t s, UgsLaunchInfo *info, const char *name) {
-    constexpr bool kCanPad = GS == 64;
+    constexpr bool kCanPad = GS == 64;      // (padded rows for the 8- and 16-lane tiers were measured in round 4: no gain on the PROTEINS- and MUTAG-shaped batches, +5 us on the QM9-shaped one)
     constexpr int GROUPS = BLOCK / GS;
     const int64_t work = a.in_list ? (int64_t)cus * blocks_per_cu * GROUPS : a.row_count;   // list length unknown on the host
     int64_t grid = (work + GROUPS - 1) / GROUPS;
