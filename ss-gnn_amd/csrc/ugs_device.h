@@ -65,7 +65,7 @@ struct UgsWalkArgs {
     int32_t m;               // samples per graph
     int32_t k;
     int32_t mode;            // UGS_MODE_* / UGS_EDGE_* (0 local, 1 flat, 2 global)
-    int32_t pad;             // UGS_SMALL_CAP: first-tier launch of tier S in its 32-candidate form; UGS_WIDE_LANES: tier S with 16 lanes per walk
+    int32_t pad;             // UGS_SMALL_CAP: first-tier launch of tier S in its 32-candidate form; UGS_WIDE_LANES: tier S with 16 lanes per walk (the two may be ORed)
     int64_t extra_node_off;  // handle API "global": base_offset
     uint64_t seed64;         // (uint64_t)(int64_t)seed
     const uint64_t *seed_ptr;// if not NULL the seed is read from here (captured HIP graphs: the value changes between replays)

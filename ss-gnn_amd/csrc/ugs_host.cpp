@@ -933,7 +933,8 @@ TierChoice choose_tier(ugs_plan *p, int k) {
               std::getenv("UGS_NO_SMALL_TIER") == nullptr;
     // tier S with 16 lanes per walk (UGS_WIDE_LANES; plan_walk_impl takes it for launches that fit the GPU at once): only where no walk
     // can be handed on with 16-lane chunks either
-    t.wide = t.first == UGS_TIER_S && !t.small && bound <= UGS_TIER_CAP[UGS_TIER_S] && bound + 1 + UGS_WIDE_LANES <= UGS_TIER_HASH_LIMIT[UGS_TIER_S];
+    t.wide = t.first == UGS_TIER_S && (t.small ? bound + 1 + UGS_WIDE_LANES <= UGS_SMALL_HASH_LIMIT
+                                               : bound <= UGS_TIER_CAP[UGS_TIER_S] && bound + 1 + UGS_WIDE_LANES <= UGS_TIER_HASH_LIMIT[UGS_TIER_S]);
     p->tiers[k] = t;
     return t;
 }
@@ -1844,7 +1845,7 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
     }
     a.work_next = dyn ? static_cast<unsigned long long *>(plan->work.p) + 0 : nullptr;
     if (tc.small) a.pad = UGS_SMALL_CAP;
-    else if (tc.wide && !dyn && std::getenv("UGS_NO_WIDE_TIER") == nullptr /* read per call: tests and A/Bs toggle it */ && row_count <= (int64_t)plan->cus * 3 /* blocks per CU, UGS_BLOCKS_S */ * UGS_WIDE_LANES) a.pad = UGS_WIDE_LANES;
+    if (tc.wide && !dyn && std::getenv("UGS_NO_WIDE_TIER") == nullptr /* read per call: tests and A/Bs toggle it */ && row_count <= (int64_t)plan->cus * 3 /* blocks per CU, UGS_BLOCKS_S */ * UGS_WIDE_LANES) a.pad |= UGS_WIDE_LANES;       // (UGS_SMALL_CAP | UGS_WIDE_LANES: both)
     // ugs_plan_step: the fill kernel can turn the counts into edge_ptr itself when the walk leaves the sums of 8 rows beside them --
     // 8-lane tier, rows taken by index (static split), no walk handed on, no capture in progress, a row count the fill's blocks can
     // add up in a few dozen loads per thread

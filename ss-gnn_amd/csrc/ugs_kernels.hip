@@ -2165,6 +2165,7 @@ hipError_t ugs_launch_walk(const UgsWalkArgs &a, int tier, int cus, int share_pe
     case UGS_TIER_S:
         // graphs of at most 33 vertices (QM9-, MUTAG-sized): 32 candidates per walk, 27 KB of LDS and 95 VGPRs per block -- five blocks
         // per CU instead of three (the QM9-shaped batch of 65 536 rows takes two trips instead of three)
+        if (a.pad == (UGS_SMALL_CAP | UGS_WIDE_LANES) && !a.in_list) return launch_lds<UGS_WIDE_LANES, UGS_SMALL_CAP, 256>(a, cus, part(5), s, info, "ugs_walk_lds<16,32>");
         if (a.pad == UGS_SMALL_CAP && !a.in_list) return launch_lds<8, UGS_SMALL_CAP, 256>(a, cus, part(5), s, info, "ugs_walk_lds<8,32>");
         // 16 lanes per walk where the host asks for them: a batch whose walks are all resident at once is bound by ONE walk's
         // latency -- four walks per wave diverge less than eight and a stage has half the elements per lane (PROTEINS-shaped batch of

@@ -646,7 +646,7 @@ def test_whole_batch_index_on_a_batch_hashed_in_chunks(product, orc):
 
 @pytest.mark.parametrize("fused", [True, False])
 def test_tier_s_with_16_lanes_per_walk_gives_the_oracle_rows(fused, monkeypatch):
-    """Batches of small graphs whose walks are all resident at once run with 16 lanes per walk (ugs_walk_lds<16,64>; 8 lanes
+    """Batches of small graphs whose walks are all resident at once run with 16 lanes per walk (ugs_walk_lds<16,64> / <16,32>; 8 lanes
     otherwise and with UGS_NO_WIDE_TIER=1): same rows as the oracle and as the 8-lane form, with and without the scan folded into the
     fill (the 16-lane form leaves the sums of 8 rows through two waves), row ranges that end inside a block of 16 rows."""
     import torch
@@ -657,7 +657,9 @@ def test_tier_s_with_16_lanes_per_walk_gives_the_oracle_rows(fused, monkeypatch)
         monkeypatch.setenv("UGS_NO_FUSED_SCAN", "1")
     torch.cuda.set_device(0)
     ugs_sampler.clear_cache()
-    for (ei, ptr), k, m in [(wl.tu_batch(39, 73, 32), 6, 256), (wl.tu_batch(45, 90, 5), 7, 37), (wl.tu_batch(60, 120, 8), 5, 500)]:
+    # (the last two: graphs of at most 33 vertices -- the 32-candidate form, ugs_walk_lds<16,32> / <8,32>)
+    for (ei, ptr), k, m in [(wl.tu_batch(39, 73, 32), 6, 256), (wl.tu_batch(45, 90, 5), 7, 37), (wl.tu_batch(60, 120, 8), 5, 500),
+                            (wl.tu_batch(18, 20, 32), 4, 32), (wl.tu_batch(18, 19, 9), 5, 300)]:
         G = len(ptr) - 1
         rows_all = G * m
         want = oracle.sample_batch(ei, ptr, m, k, "sample", 11)
@@ -670,10 +672,10 @@ def test_tier_s_with_16_lanes_per_walk_gives_the_oracle_rows(fused, monkeypatch)
             plan = ugs_sampler.Plan.from_batch(torch.from_numpy(ei), torch.from_numpy(ptr), k)
             got = []
             for rb, rc in [(0, rows_all), (3, rows_all - 9), (rows_all - 21, 21), (0, 15), (0, 17)]:
-                nodes, eptr, eidx, esrc = plan.step(m, "sample", 11, rb, rc)
+                nodes, eptr, eidx, esrc = plan.step(m, "sample", 11, rb, rc, edge_capacity=int(np.asarray(want[2])[-1]) + 8)
                 total = int(eptr[-1].item())
                 kern = plan.last_launch()["kernel"]
-                assert kern.startswith("ugs_walk_lds<16,64>" if form == "wide" and rc <= 256 * 3 * 16 else "ugs_walk_lds<8,64>"), (kern, form, rc)
+                assert kern.startswith("ugs_walk_lds<16," if form == "wide" and rc <= 256 * 3 * 16 else "ugs_walk_lds<8,"), (kern, form, rc)
                 assert np.array_equal(nodes.cpu().numpy(), np.asarray(want[0])[rb:rb + rc])
                 lo, hi = int(np.asarray(want[2])[rb]), int(np.asarray(want[2])[rb + rc])
                 assert total == hi - lo
