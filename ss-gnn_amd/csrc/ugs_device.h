@@ -121,6 +121,15 @@ struct UgsFillArgs {
     // tiles of 32 rows, a tile's offset from the sums of 8 rows the walk kernel left
     int64_t *edge_ptr_out;              // [row_count + 1], written by the kernel (NULL: edge_ptr above is read)
     const uint32_t *wsum;               // [ceil(row_count / 8)]: UgsWalkArgs::wsum of the walk of the same rows
+    // ugs_fill_scan for the library's own jobs (the drop-in call): the edge buffers are ONE staging area of `packed_cap` int64 words and
+    // the kernel lays the outputs out for the total it computes itself -- edge_index [2, total] and edge_src [total] behind it, what
+    // the caller's tensors look like, so that they leave in one copy -- or writes nothing if 3 * total exceeds the capacity (the host
+    // sees the total and fills the ordinary way).  The block that owns the last tile hands the total to the host as soon as it
+    // knows it (pinned words, epoch protocol of the scan kernels), before it fills its rows.
+    int64_t packed_cap;                 // 0: off (edge_index / ld / edge_src as given)
+    int64_t *h_total;
+    uint32_t *h_flag;
+    uint32_t epoch;
 };
 
 struct UgsLaunchInfo {

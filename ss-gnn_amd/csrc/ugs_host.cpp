@@ -1849,7 +1849,7 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
     // ugs_plan_step: the fill kernel can turn the counts into edge_ptr itself when the walk leaves the sums of 8 rows beside them --
     // 8-lane tier, rows taken by index (static split), no walk handed on, no capture in progress, a row count the fill's blocks can
     // add up in a few dozen loads per thread
-    const bool defer = defer_scan && !total_edges_host && tc.first == UGS_TIER_S && !may_overflow && !dyn && row_count <= 131072 && !capturing(s) &&
+    const bool defer = defer_scan && tc.first == UGS_TIER_S && !may_overflow && !dyn && row_count <= 131072 && !capturing(s) &&
                        std::getenv("UGS_NO_FUSED_SCAN") == nullptr;
     if (defer) {
         if (int rc = ensure(plan->tiles, std::max<size_t>((size_t)((row_count + 7) / 8) * sizeof(uint32_t), 4096), plan->device, plan)) return rc;
@@ -1898,7 +1898,7 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
     // API gets its outputs from later operations on the same stream, so nothing else needs the stream to be idle here.  Not while rows
     // may have been handed on (the overflow counters are read back with the total) and not under UGS_DEBUG.
     bool polled = false;
-    if (poll_total && total_edges_host && !may_overflow && !debug_on() && !capturing(s) && !defer_scan) {
+    if (poll_total && total_edges_host && !may_overflow && !debug_on() && !capturing(s) && !defer) {
         if (!plan->pin_slot) plan->pin_slot = pin_slot_get();
         polled = plan->pin_slot != nullptr;
     }
@@ -1912,6 +1912,7 @@ static int plan_walk_impl(ugs_plan *plan, int m_per_graph, int k, int mode, int6
     } else HIP_TRY(ugs_launch_scan(static_cast<const uint32_t *>(plan->counts.p), row_count, d_edge_ptr, static_cast<int64_t *>(plan->scantmp.p), s));
     HIP_TRY(ev_end(plan, s));
     if (int rc = plan_leave(plan, s)) return rc;
+    if (defer) return UGS_OK;                   // the caller's fill kernel scans (and, for the library's jobs, reports the total)
     if (polled) {
         HIP_TRY(wait_signal(reinterpret_cast<volatile uint32_t *>(plan->pin_slot + 8), plan->pin_epoch, s));
         *total_edges_host = *reinterpret_cast<volatile int64_t *>(plan->pin_slot);
@@ -2212,6 +2213,10 @@ struct ugs_job {
     bool batch = false;
     PoolBuf nodes;                     // nodes [rows, k] and, right behind it, edge_ptr [rows + 1]: one buffer, so that a caller whose
     int64_t *d_eptr = nullptr;         // output tensors are adjacent too gets both with one copy
+    // batches of small graphs: begin ran walk + fill as one step (scan folded into the fill) into this staging -- edge_index [2, total]
+    // and edge_src [total] laid out for the total the kernel found -- and finish only copies out
+    PoolBuf packed;
+    bool packed_ok = false;
     // epsilon_uniform path
     bool eps = false;
     PoolBuf eps_blob;                  // pooled: hipMalloc/hipFree per call cost milliseconds once the process holds large plans
@@ -2223,10 +2228,54 @@ namespace {
 void free_job(ugs_job *j) {
     if (!j) return;
     pool_put(j->nodes);
+    pool_put(j->packed);
     pool_put(j->eps_counts); pool_put(j->eps_scantmp);
     pool_put(j->eps_blob);
     plan_unref(j->plan);
     delete j;
+}
+
+// second launch of a job's step (see begin_common): ugs_fill_scan into the job's staging, total through the pinned slot of the plan
+int packed_fill(ugs_job *j, int64_t cap3) {
+    ugs_plan *plan = j->plan;
+    hipStream_t s = j->dc.stream;
+    if (int rc = pool_get((size_t)cap3 * sizeof(int64_t), j->dc.id, j->packed)) return rc;
+    std::unique_lock<std::mutex> lk(plan->mu);
+    if (int rc = plan_enter(plan, s)) return rc;
+    if (!plan->pin_slot) plan->pin_slot = pin_slot_get();
+    UgsFillArgs a{};
+    a.plan = plan->dev;
+    a.m = j->m; a.k = j->k; a.mode = j->mode;
+    a.extra_node_off = j->extra;
+    a.row_begin = 0; a.row_count = j->rows;
+    a.nodes = static_cast<const int64_t *>(j->nodes.p); a.edge_ptr = j->d_eptr; a.edge_ptr_out = j->d_eptr;
+    a.edge_index = static_cast<int64_t *>(j->packed.p); a.ld = 0; a.edge_src = nullptr;     // set by the kernel (packed_cap)
+    a.packed_cap = cap3;
+    a.counts = static_cast<const uint32_t *>(plan->counts.p);
+    a.wsum = static_cast<const uint32_t *>(plan->tiles.p);
+    const bool poll = plan->pin_slot != nullptr;
+    if (poll) {
+        uint32_t ep = g_pin_epoch.fetch_add(1) + 1;
+        if (ep == 0) ep = g_pin_epoch.fetch_add(1) + 1;
+        plan->pin_epoch = ep;
+        a.h_total = reinterpret_cast<int64_t *>(plan->pin_slot); a.h_flag = reinterpret_cast<uint32_t *>(plan->pin_slot + 8); a.epoch = ep;
+    }
+    HIP_TRY(ev_begin(plan, 2, s));
+    HIP_TRY(ugs_launch_fill_scan(a, plan->cus, s, &plan->last_fill));
+    HIP_TRY(ev_end(plan, s));
+    if (int rc = plan_leave(plan, s)) return rc;
+    if (poll) {
+        HIP_TRY(wait_signal(reinterpret_cast<volatile uint32_t *>(plan->pin_slot + 8), plan->pin_epoch, s));
+        j->total = *reinterpret_cast<volatile int64_t *>(plan->pin_slot);
+    } else {
+        int64_t tot = 0;
+        HIP_TRY(hipMemcpyAsync(&tot, j->d_eptr + j->rows, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        j->total = tot;
+    }
+    plan->last_overflow = 0;
+    j->packed_ok = 3 * j->total <= cap3;
+    return UGS_OK;
 }
 
 int begin_common(ugs_plan *plan, int m, int k, int mode, int64_t extra, int seed, bool batch, ugs_job **job_out, int64_t *total_out) {
@@ -2239,8 +2288,17 @@ int begin_common(ugs_plan *plan, int m, int k, int mode, int64_t extra, int seed
     int rc = pool_get((size_t)(j->rows * k + j->rows + 1) * sizeof(int64_t), dc.id, j->nodes);
     if (!rc) {
         j->d_eptr = static_cast<int64_t *>(j->nodes.p) + j->rows * k;
+        // Small batches: every ordered pair of a row's vertices, twice (both directions of a PyG edge are columns, and each column is
+        // symmetrised), bounds the edge entries -- if a staging of that size is affordable the step runs here in two launches, the total
+        // comes from the fill kernel's first block, and the caller allocates while the rows are being filled.  Repeated columns can
+        // exceed the bound: the kernel then writes nothing and finish fills the ordinary way.
+        const int64_t cap3 = 3 * j->rows * 2 * (int64_t)k * (int64_t)(k - 1);
+        bool want_packed = k >= 2 && j->rows > 0 && cap3 > 0 && cap3 * (int64_t)sizeof(int64_t) <= ((int64_t)192 << 20) && !debug_on() &&
+                           std::getenv("UGS_NO_PACKED_STEP") == nullptr;
+        bool deferred = false;
         rc = plan_walk_impl(plan, m, k, mode, extra, seed, nullptr, 0, j->rows, dc.stream, static_cast<int64_t *>(j->nodes.p), j->d_eptr, &j->total,
-                            nullptr, true);
+                            want_packed ? &deferred : nullptr, true);
+        if (!rc && deferred) rc = packed_fill(j, cap3);
     }
     if (rc) { free_job(j); return rc; }
     *job_out = j;
@@ -2256,7 +2314,9 @@ int finish_common(ugs_job *j, int64_t *nodes, int64_t *edge_index, int64_t *edge
     auto body = [&]() -> int {
         HIP_TRY(hipSetDevice(j->dc.id));
         int64_t *d_ei = edge_index, *d_es = edge_src;
-        if (!dst_is_device && tot > 0) {
+        const bool packed = j->packed_ok && tot > 0;                // the step already ran (begin_common): copy out of its staging
+        if (packed) { d_ei = static_cast<int64_t *>(j->packed.p); d_es = d_ei + 2 * tot; }
+        else if (!dst_is_device && tot > 0) {
             if (int r = pool_get((size_t)(3 * tot) * sizeof(int64_t), j->dc.id, e_idx)) return r;
             d_ei = static_cast<int64_t *>(e_idx.p); d_es = d_ei + 2 * tot;
         }
@@ -2265,7 +2325,7 @@ int finish_common(ugs_job *j, int64_t *nodes, int64_t *edge_index, int64_t *edge
             UgsEpsLaunch l = j->eps_l;
             l.edge_ptr = j->d_eptr; l.edge_index = d_ei; l.edge_src = d_es; l.ld = tot;
             HIP_TRY(ugs_eps_launch(l, 1, j->dc.cus, s));
-        } else if (tot > 0) {
+        } else if (tot > 0 && !packed) {
             if (!d_ei || !d_es) return fail(UGS_E_BAD_ARG, "null edge output pointer");
             if (int r = ugs_plan_fill(j->plan, j->m, j->k, j->mode, j->extra, 0, rows, s, static_cast<const int64_t *>(j->nodes.p),
                                       j->d_eptr, d_ei, tot, d_es)) return r;
@@ -2278,7 +2338,8 @@ int finish_common(ugs_job *j, int64_t *nodes, int64_t *edge_index, int64_t *edge
             if (rows * k > 0) HIP_TRY(hipMemcpyAsync(nodes, j->nodes.p, (size_t)(rows * k) * sizeof(int64_t), kind, s));
             HIP_TRY(hipMemcpyAsync(edge_ptr, j->d_eptr, (size_t)(rows + 1) * sizeof(int64_t), kind, s));
         }
-        if (!dst_is_device && tot > 0) {
+        if ((!dst_is_device || packed) && tot > 0) {
+            if (!edge_index || !edge_src) return fail(UGS_E_BAD_ARG, "null edge output pointer");
             if (edge_src == edge_index + 2 * tot) {
                 HIP_TRY(hipMemcpyAsync(edge_index, d_ei, (size_t)(3 * tot) * sizeof(int64_t), kind, s));
             } else {

@@ -2046,7 +2046,8 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill(UgsFillArgs a) {
 // (every tile of a small batch starts at once, nobody has a prefix yet: 32-40 us), tile sums + sums of groups of 64 tiles (33 us:
 // the agent-scope loads and stores that carry the sums between blocks on different XCDs cost 15 us whatever is waited for or not).
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void ugs_fill_scan(UgsFillArgs a) {
+__global__ __launch_bounds__(BLOCK) void ugs_fill_scan(UgsFillArgs a_in) {
+    UgsFillArgs a = a_in;                   // (packed form: ld and edge_src are set once the total is known)
     constexpr int GS = 8, GROUPS = BLOCK / GS;
     static_assert(GROUPS == 32, "a tile is 32 rows = four of the walk's 8-row sums");
     __shared__ uint32_t sv_all[GROUPS * UGS_KMAX];
@@ -2055,9 +2056,13 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill_scan(UgsFillArgs a) {
     __shared__ uint32_t cnt_sh[GROUPS];
     __shared__ unsigned long long excl_sh[GROUPS];
     __shared__ unsigned long long part_sh[BLOCK / 64];
+    __shared__ unsigned long long all_sh[BLOCK / 64];
     Grp<GS> g;
     g.init();
     const int gib = (int)threadIdx.x / GS;
+    const bool packed = a.packed_cap != 0;
+    const long long nw = (long long)((a.row_count + 7) / 8);             // the walk's 8-row sums
+    bool write = true;
     uint32_t *SV = sv_all + gib * UGS_KMAX;
     uint32_t *PS = ps_all + gib * (UGS_KMAX + 1);
     int64_t *R0 = r0_all + gib * UGS_KMAX;
@@ -2070,12 +2075,31 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill_scan(UgsFillArgs a) {
         const uint32_t c = in ? (a.counts[row_rel] & ~UGS_COUNT_STAGED) : 0u;
         if (g.lane == 0) cnt_sh[gib] = c;
         // everything in front of the tile: the block's threads share the walk's 8-row sums
-        unsigned long long before = 0ull;
-        for (long long i = threadIdx.x; i < 4 * tile; i += BLOCK) before += a.wsum[i];
+        unsigned long long before = 0ull, all = 0ull;
+        if (!packed) {
+            for (long long i = threadIdx.x; i < 4 * tile; i += BLOCK) before += a.wsum[i];
+        } else if (tile == (long long)blockIdx.x) {                       // packed: the sum of ALL rows too, once per block
+            for (long long i = threadIdx.x; i < nw; i += BLOCK) { const unsigned long long v = a.wsum[i]; all += v; before += i < 4 * tile ? v : 0ull; }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) all += (unsigned long long)__shfl_xor((long long)all, d, 64);
+            if ((threadIdx.x & 63) == 0) all_sh[threadIdx.x >> 6] = all;
+        } else {
+            for (long long i = threadIdx.x; i < 4 * tile; i += BLOCK) before += a.wsum[i];
+        }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) before += (unsigned long long)__shfl_xor((long long)before, d, 64);
         if ((threadIdx.x & 63) == 0) part_sh[threadIdx.x >> 6] = before;
         __syncthreads();
+        if (packed && tile == (long long)blockIdx.x) {
+            unsigned long long tot = 0ull;
+#pragma unroll
+            for (int wv = 0; wv < BLOCK / 64; ++wv) tot += all_sh[wv];
+            a.ld = (int64_t)tot;                                          // edge_index [2, total], edge_src right behind it
+            a.edge_src = a.edge_index + 2 * (int64_t)tot;
+            write = 3 * (int64_t)tot <= a.packed_cap;
+            // block 0 hands the total to the host right away: the caller allocates its tensors while the rows are being filled
+            if (blockIdx.x == 0 && threadIdx.x == 0 && a.h_total) { *a.h_total = (int64_t)tot; __threadfence_system(); *(volatile uint32_t *)a.h_flag = a.epoch; }
+        }
         if (threadIdx.x < 64) {                                       // the tile's own 32 counts
             const int lane = (int)threadIdx.x;
             const uint32_t x = lane < GROUPS ? cnt_sh[lane] : 0u;
@@ -2091,9 +2115,12 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill_scan(UgsFillArgs a) {
         const int64_t e0 = (int64_t)(front + excl_sh[gib]);
         if (in && g.lane == 0) {
             a.edge_ptr_out[row_rel] = e0;
-            if (row_rel == a.row_count - 1) a.edge_ptr_out[a.row_count] = e0 + (int64_t)c;
+            if (row_rel == a.row_count - 1) {
+                a.edge_ptr_out[a.row_count] = e0 + (int64_t)c;
+                if (a.h_total && !packed) { *a.h_total = e0 + (int64_t)c; __threadfence_system(); *(volatile uint32_t *)a.h_flag = a.epoch; }
+            }
         }
-        if (in && c != 0u) {
+        if (in && c != 0u && write) {
             const int64_t row = a.row_begin + row_rel;
             int64_t gi, i;
             if (P.num_graphs == 1) { gi = 0; i = row; }

@@ -357,6 +357,37 @@ def test_more_edge_cases_vs_oracle(product, orc):
     _same(calls, product, orc, "edge cases")
 
 
+@pytest.mark.parametrize("packed", [True, False])
+def test_drop_in_call_with_the_step_run_in_begin(packed, product, orc, monkeypatch):
+    """Batches of small graphs: the drop-in call runs walk + fill as one step while it waits for the total (the outputs staged for
+    that total, ugs_fill_scan's packed form) and only copies out afterwards -- against the oracle for every mode, a batch whose
+    repeated columns push the total past the staging's bound (the kernel writes nothing, the ordinary fill runs), rows that end
+    inside a tile, k = 2, device outputs; UGS_NO_PACKED_STEP=1 is the two-phase form."""
+    import torch
+    import ugs_sampler
+    import ugs_workloads as wl
+    if not packed:
+        monkeypatch.setenv("UGS_NO_PACKED_STEP", "1")
+    calls = []
+    for (ei, ptr), k, m in [(wl.tu_batch(39, 73, 32), 6, 64), (wl.tu_batch(18, 20, 9), 4, 77), (wl.tu_batch(25, 40, 3), 2, 11)]:
+        for mode in ("sample", "graph", "global"):
+            calls.append(dict(fn="sample_batch", edge_index=ei, ptr=ptr, m=m, k=k, mode=mode, seed=7))
+    ei, ptr = wl.tu_batch(12, 30, 8)
+    rep = np.ascontiguousarray(np.concatenate([ei] * 5, axis=1))                   # every column five times: ~5 x the entries of a simple graph
+    calls.append(dict(fn="sample_batch", edge_index=rep, ptr=ptr, m=64, k=4, mode="sample", seed=3))
+    _same(calls, product, orc, "packed step" if packed else "two-phase step")
+    import oracle
+    want = oracle.sample_batch(rep, ptr, 64, 4, "sample", 3)
+    assert int(np.asarray(want[2])[-1]) > 8 * 64 * 2 * 4 * 3, "the repeated-column batch must exceed the staging's bound"
+    # device outputs
+    dev = torch.device("cuda:0")
+    (ei, ptr), k, m = (wl.tu_batch(39, 73, 32), 6, 64)
+    got = ugs_sampler.sample_batch(torch.from_numpy(ei), torch.from_numpy(ptr), m, k, mode="graph", seed=7, device=dev)
+    want = oracle.sample_batch(ei, ptr, m, k, "graph", 7)
+    for g, w in zip(got, want):
+        assert g.device.type == "cuda" and np.array_equal(g.cpu().numpy(), np.asarray(w))
+
+
 def test_lru_eviction_with_small_cache_matches_oracle():
     """UGS_CACHE_SIZE=2 (read once per process, like the reference): evictions and re-creations with another k must follow
     the reference's LRU exactly.  Runs in a subprocess because the capacity is fixed at first use."""
