@@ -13,7 +13,7 @@ done
 PMC_MORE=1 tools/profile_pmc.sh r04_c5 > $O/pmc_c5.log 2>&1
 python3 tools/summarize_pmc.py gpurun_out/pmc_r04_c5 > $O/r04_c5_pmc_summary.json
 timeout -k 10 200 python bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_c5_plain.json 2> $O/bench_c5_plain.err
-python3 tools/traffic_from_pmc.py $O/r04_c5_pmc_summary.json $O/bench_c5_plain.json > $O/traffic.log 2>&1 && cp profiles/pmc_traffic.json $O/pmc_traffic.json
+python3 tools/traffic_from_pmc.py $O/r04_c5_pmc_summary.json $O/bench_c5_plain.json > $O/traffic.log 2>&1 && cp profiles/pmc_traffic.json $O/pmc_traffic.json   # copy it back into profiles/ (source path: profiles/r04_c5_pmc_summary.json)
 if [ -f ab/lib_stamps.so ]; then
   for w in c5_er_1m er_200000_16000000_200000_8; do STAMPS_LIB=ab/lib_stamps.so timeout -k 10 200 python tools/stamps.py $w > $O/stamps_$w.txt 2>&1; done
 fi
