@@ -2215,7 +2215,6 @@ struct ugs_job {
     int64_t *d_eptr = nullptr;         // output tensors are adjacent too gets both with one copy
     // batches of small graphs: begin ran walk + fill as one step (scan folded into the fill) into this staging -- edge_index [2, total]
     // and edge_src [total] laid out for the total the kernel found -- and finish only copies out
-    PoolBuf packed;
     bool packed_ok = false;
     // epsilon_uniform path
     bool eps = false;
@@ -2228,7 +2227,6 @@ namespace {
 void free_job(ugs_job *j) {
     if (!j) return;
     pool_put(j->nodes);
-    pool_put(j->packed);
     pool_put(j->eps_counts); pool_put(j->eps_scantmp);
     pool_put(j->eps_blob);
     plan_unref(j->plan);
@@ -2239,7 +2237,7 @@ void free_job(ugs_job *j) {
 int packed_fill(ugs_job *j, int64_t cap3) {
     ugs_plan *plan = j->plan;
     hipStream_t s = j->dc.stream;
-    if (int rc = pool_get((size_t)cap3 * sizeof(int64_t), j->dc.id, j->packed)) return rc;
+    int64_t *stg = static_cast<int64_t *>(j->nodes.p) + (j->rows * j->k + j->rows + 1);       // (begin_common sized the buffer for it)
     std::unique_lock<std::mutex> lk(plan->mu);
     if (int rc = plan_enter(plan, s)) return rc;
     if (!plan->pin_slot) plan->pin_slot = pin_slot_get();
@@ -2249,7 +2247,7 @@ int packed_fill(ugs_job *j, int64_t cap3) {
     a.extra_node_off = j->extra;
     a.row_begin = 0; a.row_count = j->rows;
     a.nodes = static_cast<const int64_t *>(j->nodes.p); a.edge_ptr = j->d_eptr; a.edge_ptr_out = j->d_eptr;
-    a.edge_index = static_cast<int64_t *>(j->packed.p); a.ld = 0; a.edge_src = nullptr;     // set by the kernel (packed_cap)
+    a.edge_index = stg; a.ld = 0; a.edge_src = nullptr;                                       // set by the kernel (packed_cap)
     a.packed_cap = cap3;
     a.counts = static_cast<const uint32_t *>(plan->counts.p);
     a.wsum = static_cast<const uint32_t *>(plan->tiles.p);
@@ -2285,16 +2283,22 @@ int begin_common(ugs_plan *plan, int m, int k, int mode, int64_t extra, int seed
     j->plan = plan; j->dc = dc; j->m = m; j->k = k; j->mode = mode; j->extra = extra; j->batch = batch;
     j->G = plan->G;
     j->rows = plan->G * (int64_t)m;
-    int rc = pool_get((size_t)(j->rows * k + j->rows + 1) * sizeof(int64_t), dc.id, j->nodes);
+    // (a job that may run the packed step keeps its edge staging right behind nodes and edge_ptr: all four outputs leave in ONE copy when
+    // the caller's tensors are adjacent too, as the Python shim's are)
+    const int64_t node_words = j->rows * k + j->rows + 1;
+    const int64_t cap3_want = 3 * j->rows * 2 * (int64_t)k * (int64_t)(k - 1);
+    const TierChoice tc0 = choose_tier(plan, k);
+    const bool may_pack = k >= 2 && j->rows > 0 && j->rows <= 131072 && tc0.first == UGS_TIER_S && tc0.second < 0 && !tc0.third_G &&
+                          cap3_want * (int64_t)sizeof(int64_t) <= ((int64_t)192 << 20) && !debug_on() && std::getenv("UGS_NO_PACKED_STEP") == nullptr;
+    int rc = pool_get((size_t)(node_words + (may_pack ? cap3_want : 0)) * sizeof(int64_t), dc.id, j->nodes);
     if (!rc) {
         j->d_eptr = static_cast<int64_t *>(j->nodes.p) + j->rows * k;
         // Small batches: every ordered pair of a row's vertices, twice (both directions of a PyG edge are columns, and each column is
         // symmetrised), bounds the edge entries -- if a staging of that size is affordable the step runs here in two launches, the total
         // comes from the fill kernel's first block, and the caller allocates while the rows are being filled.  Repeated columns can
         // exceed the bound: the kernel then writes nothing and finish fills the ordinary way.
-        const int64_t cap3 = 3 * j->rows * 2 * (int64_t)k * (int64_t)(k - 1);
-        bool want_packed = k >= 2 && j->rows > 0 && cap3 > 0 && cap3 * (int64_t)sizeof(int64_t) <= ((int64_t)192 << 20) && !debug_on() &&
-                           std::getenv("UGS_NO_PACKED_STEP") == nullptr;
+        const int64_t cap3 = cap3_want;
+        const bool want_packed = may_pack;
         bool deferred = false;
         rc = plan_walk_impl(plan, m, k, mode, extra, seed, nullptr, 0, j->rows, dc.stream, static_cast<int64_t *>(j->nodes.p), j->d_eptr, &j->total,
                             want_packed ? &deferred : nullptr, true);
@@ -2315,7 +2319,7 @@ int finish_common(ugs_job *j, int64_t *nodes, int64_t *edge_index, int64_t *edge
         HIP_TRY(hipSetDevice(j->dc.id));
         int64_t *d_ei = edge_index, *d_es = edge_src;
         const bool packed = j->packed_ok && tot > 0;                // the step already ran (begin_common): copy out of its staging
-        if (packed) { d_ei = static_cast<int64_t *>(j->packed.p); d_es = d_ei + 2 * tot; }
+        if (packed) { d_ei = static_cast<int64_t *>(j->nodes.p) + (rows * k + rows + 1); d_es = d_ei + 2 * tot; }
         else if (!dst_is_device && tot > 0) {
             if (int r = pool_get((size_t)(3 * tot) * sizeof(int64_t), j->dc.id, e_idx)) return r;
             d_ei = static_cast<int64_t *>(e_idx.p); d_es = d_ei + 2 * tot;
@@ -2331,7 +2335,12 @@ int finish_common(ugs_job *j, int64_t *nodes, int64_t *edge_index, int64_t *edge
                                       j->d_eptr, d_ei, tot, d_es)) return r;
         }
         const hipMemcpyKind kind = dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-        // adjacent outputs (the Python shim carves its tensors out of one allocation) travel in one copy each
+        // adjacent outputs (the Python shim carves its tensors out of one allocation) travel in one copy each -- or all in one
+        if (packed && edge_ptr == nodes + rows * k && edge_index == edge_ptr + rows + 1 && edge_src == edge_index + 2 * tot) {
+            // (the same copy through a kernel storing to the pinned tensors was measured: 103 against 96 us for the 2.3 MB of the
+            // PROTEINS-shaped call -- the DMA copy stays)
+            HIP_TRY(hipMemcpyAsync(nodes, j->nodes.p, (size_t)(rows * k + rows + 1 + 3 * tot) * sizeof(int64_t), kind, s));
+        } else {
         if (edge_ptr == nodes + rows * k) {
             HIP_TRY(hipMemcpyAsync(nodes, j->nodes.p, (size_t)(rows * k + rows + 1) * sizeof(int64_t), kind, s));
         } else {
@@ -2346,6 +2355,7 @@ int finish_common(ugs_job *j, int64_t *nodes, int64_t *edge_index, int64_t *edge
                 HIP_TRY(hipMemcpyAsync(edge_index, d_ei, (size_t)(2 * tot) * sizeof(int64_t), kind, s));
                 HIP_TRY(hipMemcpyAsync(edge_src, d_es, (size_t)tot * sizeof(int64_t), kind, s));
             }
+        }
         }
         if (sample_ptr) {
             std::vector<int64_t> sp((size_t)j->G + 1);
