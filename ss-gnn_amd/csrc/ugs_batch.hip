@@ -361,6 +361,18 @@ __global__ __launch_bounds__(kBpBlock) void ugs_bp_roots(BpRoots a) {
         SDEG[vi] = (uint16_t)c;
         int cnt = 1;
         L[0] = (uint16_t)v;
+        if (n <= 64) {                                                   // the reached set as a register bit mask (same visits, same order: the count is all that is used)
+            unsigned long long reached = 1ull << v;
+            for (int h = 0; h < cnt && cnt < k; ++h) {
+                const int u = L[h];
+                for (int p = RP[u], e = RP[u + 1]; p < e && cnt < k; ++p) {
+                    const int w = NBR[p];
+                    if ((int)RNK[w] < vi || ((reached >> w) & 1ull)) continue;
+                    reached |= 1ull << w;
+                    L[cnt++] = (uint16_t)w;
+                }
+            }
+        } else
         for (int h = 0; h < cnt && cnt < k; ++h) {
             const int u = L[h];
             for (int p = RP[u], e = RP[u + 1]; p < e && cnt < k; ++p) {
@@ -396,19 +408,28 @@ __global__ __launch_bounds__(kBpBlock) void ugs_bp_roots(BpRoots a) {
             int nl = 0, nh = 0;
             for (int i = 0; i < n; ++i) { if (P[i] < 1.0) LO[nl++] = (uint16_t)i; else HI[nh++] = (uint16_t)i; }
             if (nl > 0 && nh > 0) {
+                // One lane, a chain of dependent LDS reads per step (stack top, its weight): the entries the NEXT step will need are
+                // requested before this step's arithmetic -- the next small one is either the large one just demoted (its weight is in a
+                // register) or the entry below the top, the next large one the entry below the current.  Same reads, same arithmetic,
+                // same order of operations as the host's build_alias (reference include/sampler.hpp:44-69).
                 int l = HI[nh - 1];
                 double pl = P[l];
+                int s = LO[nl - 1];
+                double ps = P[s];
                 while (nl > 0 && nh > 0) {
-                    const int s = LO[--nl];
-                    const double ps = P[s];
+                    --nl;
+                    const int s_below = nl > 0 ? LO[nl - 1] : 0;
+                    const int l_below = nh > 1 ? HI[nh - 2] : 0;
+                    const double ps_below = P[s_below], pl_below = P[l_below];
                     ALI[s] = (uint16_t)l;
                     pl = (pl + ps) - 1.0;
                     if (pl < 1.0) {
                         P[l] = pl;
                         --nh;
                         LO[nl++] = (uint16_t)l;
-                        if (nh > 0) { l = HI[nh - 1]; pl = P[l]; }
-                    }
+                        s = l; ps = pl;                                  // popped next: the demoted one
+                        l = l_below; pl = pl_below;                      // (unused when nh == 0)
+                    } else { s = s_below; ps = ps_below; }
                 }
             }
             for (int i = 0; i < nh; ++i) P[HI[i]] = 1.0;              // leftovers of either stack accept with probability 1
