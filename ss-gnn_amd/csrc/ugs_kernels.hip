@@ -2077,16 +2077,31 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill_scan(UgsFillArgs a_in) {
         const uint32_t c = in ? (a.counts[row_rel] & ~UGS_COUNT_STAGED) : 0u;
         if (g.lane == 0) cnt_sh[gib] = c;
         // everything in front of the tile: the block's threads share the walk's 8-row sums
+        // (16-byte loads, eight of them in flight per thread: one word per trip of a rolled loop was one L2 round trip per 256 words --
+        // 32 of them in a row for the last tiles of the QM9-shaped batch, most of the kernel's 20 us)
         unsigned long long before = 0ull, all = 0ull;
-        if (!packed) {
-            for (long long i = threadIdx.x; i < 4 * tile; i += BLOCK) before += a.wsum[i];
-        } else if (tile == (long long)blockIdx.x) {                       // packed: the sum of ALL rows too, once per block
-            for (long long i = threadIdx.x; i < nw; i += BLOCK) { const unsigned long long v = a.wsum[i]; all += v; before += i < 4 * tile ? v : 0ull; }
+        const uint4 *w4 = reinterpret_cast<const uint4 *>(a.wsum);
+        for (long long t0 = 0; t0 < tile; t0 += 8 * BLOCK) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const long long t = t0 + u * BLOCK + threadIdx.x; v[u] = t < tile ? w4[t] : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) before += (unsigned long long)v[u].x + v[u].y + v[u].z + v[u].w;
+        }
+        if (packed && tile == (long long)blockIdx.x) {                    // packed: the sum of ALL rows too, once per block
+            all = before;
+            const long long n4 = nw >> 2;
+            for (long long t0 = tile; t0 < n4; t0 += 8 * BLOCK) {
+                uint4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const long long t = t0 + u * BLOCK + threadIdx.x; v[u] = t < n4 ? w4[t] : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) all += (unsigned long long)v[u].x + v[u].y + v[u].z + v[u].w;
+            }
+            if ((long long)threadIdx.x < nw - 4 * n4) all += a.wsum[4 * n4 + threadIdx.x];        // the last one to three words
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) all += (unsigned long long)__shfl_xor((long long)all, d, 64);
             if ((threadIdx.x & 63) == 0) all_sh[threadIdx.x >> 6] = all;
-        } else {
-            for (long long i = threadIdx.x; i < 4 * tile; i += BLOCK) before += a.wsum[i];
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) before += (unsigned long long)__shfl_xor((long long)before, d, 64);
