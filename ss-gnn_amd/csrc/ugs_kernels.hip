@@ -2137,6 +2137,8 @@ __global__ __launch_bounds__(BLOCK) void ugs_fill_scan(UgsFillArgs a_in) {
                 if (a.h_total && !packed) { *a.h_total = e0 + (int64_t)c; __threadfence_system(); *(volatile uint32_t *)a.h_flag = a.epoch; }
             }
         }
+        // (QM9-shaped batch, 22.6 us: 9.9 us without the rows' fill -- counts, prefix, edge_ptr and the launch -- and 12.7 us of fill_row's three
+        // dependent global reads per row: nodes -> row pointers -> adjacency entries)
         if (in && c != 0u && write) {
             const int64_t row = a.row_begin + row_rel;
             int64_t gi, i;
