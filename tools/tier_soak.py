@@ -1,12 +1,12 @@
 """One-off soak of the walk tiers added in round 3 (W: 704 candidates, two-pass final; V: 1408 candidates, three-pass final): random
 multigraphs whose walks end with hundreds to thousands of candidates, every call forced into one tier (rows that outgrow it are handed
-on by the library), all five tensors against the oracle.  usage: tools/tier_soak.py [calls per tier]"""
+on by the library), all five tensors against the oracle.  usage: tools/tier_soak.py [calls per tier] [tiers, e.g. 1,2,4]"""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, p) for p in ("tests", "oracle", "ss-gnn_amd")]
 import numpy as np, torch, oracle, ugs_sampler
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 120
-for tier in ("2", "4", "3", "5"):
+for tier in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("2", "4", "3", "5")):
     os.environ["UGS_FORCE_TIER"] = tier
     rng = random.Random(4000 + int(tier))
     handed = 0
