@@ -646,7 +646,18 @@ def bench_drop_in(name, ugs_sampler, ei_t, ptr_t, m, k, mode, dev, reps):
     tensors in -- (a) pinned host tensors out (SURVEY.md 8(d) primary definition: outputs host-visible), (b) device tensors out."""
     import torch
     rows = (ptr_t.numel() - 1) * m
-    ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode=mode, seed=42)
+    streamed = rows >= ugs_sampler._STREAM_MIN_ROWS and not os.environ.get("UGS_NO_STREAMED_CALL")
+    two_phase_ms = None
+    if streamed:        # the two-phase form of the same call (walks, then fill, then copy-out), for the record
+        os.environ["UGS_NO_STREAMED_CALL"] = "1"
+        ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode=mode, seed=42)
+        t = time.perf_counter()
+        for r in range(reps):
+            ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode=mode, seed=42 + r)
+        two_phase_ms = round((time.perf_counter() - t) / reps * 1e3, 3)
+        del os.environ["UGS_NO_STREAMED_CALL"]
+    for r in range(2):  # (a shape's first call sizes the edge buffers of the later ones: ugs_sampler._sample_batch_streamed)
+        ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode=mode, seed=40 + r)
     t = time.perf_counter()
     for r in range(reps):
         ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode=mode, seed=42 + r)
@@ -661,6 +672,7 @@ def bench_drop_in(name, ugs_sampler, ei_t, ptr_t, m, k, mode, dev, reps):
     del o
     return {"workload": name, "rows": rows, "host_visible_ms": round(dt_host * 1e3, 3), "host_visible_subgraphs_per_s": round(rows / dt_host, 1),
             "device_out_ms": round(dt_dev * 1e3, 3), "device_out_subgraphs_per_s": round(rows / dt_dev, 1), "reps": reps,
+            "host_visible_streamed": bool(streamed), "host_visible_two_phase_ms": two_phase_ms,
             "note": "host tensors in every call (the reference's interface): per call the library hashes the batch's bytes (a batch seen before is matched as "
                     "a whole; the per-graph LRU is touched as the general path would), samples, and copies out"}
 

@@ -35,6 +35,7 @@ extern "C" {
 #define UGS_E_HIP (-6)              /* a HIP runtime call failed */
 #define UGS_E_UNSUPPORTED (-7)      /* outside the limits documented in DESIGN.md (k > 32, nnz >= 2^31 per plan, ...) */
 #define UGS_E_EDGE_SRC (-8)         /* edge_src range check                reference src/ugs_sampler_batch_extension.cpp:213-222 */
+#define UGS_E_CAPACITY (-9)         /* ugs_sample_batch_stream: the call produced more edge entries than edge_capacity */
 
 /* edge_mode of sample()            reference src/sampler.cpp:95 ("local" | "flat" | "global") */
 #define UGS_EDGE_LOCAL 0
@@ -100,6 +101,19 @@ int ugs_sample_batch_begin(const int64_t *edge_index, int64_t row_stride, int64_
 int ugs_sample_batch_finish(ugs_job *job, int64_t *nodes, int64_t *edge_index, int64_t *edge_ptr,
                             int64_t *sample_ptr, int64_t *edge_src_global, int dst_is_device);
 int ugs_job_cancel(ugs_job *job);
+
+/* The same call (reference src/ugs_sampler_batch_extension.cpp:77-299, same LRU, same results) for LARGE host-visible batches,
+ * in one piece: the caller hands over its (pinned) host buffers up front -- nodes[G*m,k], edge_ptr[G*m+1], sample_ptr[G+1],
+ * edge_src_global[edge_capacity] and edge_index_out[2*edge_capacity] -- and the rows are sampled in chunks whose results cross
+ * PCIe on a second stream while the next chunk walks (the two-phase call copies only after the last walk).  On return
+ * *total_edges_out = total, edge_index_out holds [2, total] CONTIGUOUSLY at its start (row 1 begins at edge_index_out + total) and
+ * edge_src_global[total].  edge_capacity is the caller's estimate (e.g. the total of an earlier call on the same batch plus a
+ * margin); a call that needs more returns UGS_E_CAPACITY with the buffers' contents undefined -- repeat it through
+ * ugs_sample_batch_begin / _finish.  UGS_STREAM_CHUNK_ROWS overrides the chunk size (default: an eighth of the rows, >= 65536). */
+int ugs_sample_batch_stream(const int64_t *edge_index, int64_t row_stride, int64_t num_cols, const int64_t *ptr,
+                            int64_t num_graphs, int m_per_graph, int k, int mode, int seed, int64_t edge_capacity,
+                            int64_t *nodes, int64_t *edge_index_out, int64_t *edge_ptr, int64_t *sample_ptr,
+                            int64_t *edge_src_global, int64_t *total_edges_out);
 
 /* LRU of preprocessing handles used by ugs_sample_batch_* (capacity from UGS_CACHE_SIZE, default 1000;
  * reference src/ugs_sampler_batch_extension.cpp:15-38).  Clearing it is the equivalent of a fresh process. */

@@ -103,3 +103,17 @@ hipError_t ugs_launch_collate_unpack(const void *d_msgs, int world, int64_t msg_
     }
     return hipGetLastError();
 }
+
+// ---- streamed host-visible calls (ugs_sample_batch_stream): a chunk's edge_ptr starts at 0; the caller's starts at the chunk's base ----
+namespace {
+__global__ __launch_bounds__(256) void ugs_rebase_edge_ptr(const int64_t *__restrict__ in, int64_t *__restrict__ out, int64_t n, int64_t base) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i] + base;
+}
+}  // namespace
+
+hipError_t ugs_launch_rebase_edge_ptr(const int64_t *in, int64_t *out, int64_t n, int64_t base, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ugs_rebase_edge_ptr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n, base);
+    return hipGetLastError();
+}

@@ -2412,6 +2412,97 @@ int ugs_sample_batch_finish(ugs_job *job, int64_t *nodes, int64_t *edge_index, i
 
 int ugs_job_cancel(ugs_job *job) { free_job(job); return UGS_OK; }
 
+// ---- the whole sample_batch call with the copy-out running BESIDE the walks (large host-visible calls) ------------------------------
+// The two-phase call is walk (all rows) -> total -> caller allocates -> fill -> copy out: for a million rows the 400 MB of int64
+// results cross PCIe for longer than the walks take, one after the other.  Here the caller hands over its buffers up front (edge
+// buffers by a capacity it expects, e.g. the previous call's total plus a margin), the rows go through walk / scan / fill in chunks on
+// the job stream, and every finished chunk leaves on a second stream while the next one walks.  Row 1 of edge_index [2, total] starts
+// at `total`, known with the last chunk only: that half is kept in the device staging and leaves at the end.
+namespace {
+std::mutex g_copy_mu;
+std::map<int, hipStream_t> &g_copy_streams = *new std::map<int, hipStream_t>();
+int copy_stream(int dev, hipStream_t &out) {
+    std::lock_guard<std::mutex> lk(g_copy_mu);
+    auto it = g_copy_streams.find(dev);
+    if (it == g_copy_streams.end()) {
+        hipStream_t c = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+        it = g_copy_streams.emplace(dev, c).first;
+    }
+    out = it->second;
+    return UGS_OK;
+}
+}  // namespace
+
+int ugs_sample_batch_stream(const int64_t *edge_index, int64_t row_stride, int64_t num_cols, const int64_t *ptr, int64_t num_graphs,
+                            int m_per_graph, int k, int mode, int seed, int64_t edge_capacity, int64_t *nodes, int64_t *edge_index_out,
+                            int64_t *edge_ptr, int64_t *sample_ptr, int64_t *edge_src_global, int64_t *total_edges_out) {
+    if (mode < 0 || mode > 2) return fail(UGS_E_BAD_MODE, "mode must be one of: 'sample', 'graph', 'global'");
+    if (m_per_graph < 0) return fail(UGS_E_BAD_ARG, "m_per_graph must be >= 0");
+    if (k < 1) return fail(UGS_E_BAD_ARG, "k must be >= 1");
+    if (k > UGS_KMAX) return fail(UGS_E_UNSUPPORTED, "k > 32 is not supported by the HIP sampler");
+    if (edge_capacity < 0 || !edge_ptr || !total_edges_out) return fail(UGS_E_BAD_ARG, "null output pointer or negative edge_capacity");
+    ugs_plan *plan = nullptr;
+    if (int rc = ugs_plan_create_batch(edge_index, row_stride, num_cols, ptr, num_graphs, k, &plan)) return rc;
+    DeviceCtx dc;
+    if (int rc = device_ctx(dc)) { plan_unref(plan); return rc; }
+    const int64_t G = plan->G, rows = G * (int64_t)m_per_graph, cap = edge_capacity;
+    if (rows > 0 && (!nodes || (cap > 0 && (!edge_index_out || !edge_src_global)))) { plan_unref(plan); return fail(UGS_E_BAD_ARG, "null output pointer"); }
+    int64_t chunk = (rows + 7) / 8;                                   // eight chunks: the first copy starts after an eighth of the walks
+    if (chunk < 65536) chunk = 65536;
+    if (const char *e = std::getenv("UGS_STREAM_CHUNK_ROWS")) { const int64_t v = std::atoll(e); if (v > 0) chunk = v; }   // (tests: many chunks of a small call)
+    const int64_t nchunks = rows > 0 ? (rows + chunk - 1) / chunk : 0;
+    hipStream_t s = dc.stream, cs = nullptr;
+    PoolBuf d_nodes_b, d_eptr_b, d_loc_b, d_edges_b;
+    std::vector<hipEvent_t> evs;
+    int64_t base = 0;
+    auto body = [&]() -> int {
+        HIP_TRY(hipSetDevice(dc.id));
+        if (int rc = copy_stream(dc.id, cs)) return rc;
+        if (sample_ptr) for (int64_t g = 0; g <= G; ++g) sample_ptr[g] = g * (int64_t)m_per_graph;
+        if (rows == 0) { edge_ptr[0] = 0; *total_edges_out = 0; return UGS_OK; }
+        if (int rc = pool_get((size_t)(rows * k) * sizeof(int64_t), dc.id, d_nodes_b)) return rc;
+        if (int rc = pool_get((size_t)(rows + 1) * sizeof(int64_t), dc.id, d_eptr_b)) return rc;
+        if (int rc = pool_get((size_t)(chunk + 1) * sizeof(int64_t), dc.id, d_loc_b)) return rc;
+        if (cap > 0) if (int rc = pool_get((size_t)(3 * cap) * sizeof(int64_t), dc.id, d_edges_b)) return rc;
+        int64_t *d_nodes = static_cast<int64_t *>(d_nodes_b.p), *d_eptr = static_cast<int64_t *>(d_eptr_b.p), *d_loc = static_cast<int64_t *>(d_loc_b.p);
+        int64_t *d_ei = static_cast<int64_t *>(d_edges_b.p), *d_es = d_ei ? d_ei + 2 * cap : nullptr;
+        for (int64_t c = 0; c < nchunks; ++c) {
+            const int64_t r0 = c * chunk, rc_rows = std::min(chunk, rows - r0);
+            const bool last = c + 1 == nchunks;
+            int64_t tot = 0;
+            if (int rc = plan_walk_impl(plan, m_per_graph, k, mode, 0, seed, nullptr, r0, rc_rows, s, d_nodes + r0 * k, d_loc, &tot, nullptr, true)) return rc;
+            if (base + tot > cap) { *total_edges_out = base + tot; return fail(UGS_E_CAPACITY, "edge_capacity too small for this call's edge entries"); }
+            if (tot > 0)
+                if (int rc = ugs_plan_fill(plan, m_per_graph, k, mode, 0, r0, rc_rows, s, d_nodes + r0 * k, d_loc, d_ei + base, cap, d_es + base)) return rc;
+            HIP_TRY(ugs_launch_rebase_edge_ptr(d_loc, d_eptr + r0, rc_rows + (last ? 1 : 0), base, s));
+            hipEvent_t ev = nullptr;
+            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            evs.push_back(ev);
+            HIP_TRY(hipEventRecord(ev, s));
+            HIP_TRY(hipStreamWaitEvent(cs, ev, 0));
+            HIP_TRY(hipMemcpyAsync(nodes + r0 * k, d_nodes + r0 * k, (size_t)(rc_rows * k) * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
+            HIP_TRY(hipMemcpyAsync(edge_ptr + r0, d_eptr + r0, (size_t)(rc_rows + (last ? 1 : 0)) * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
+            if (tot > 0) {
+                HIP_TRY(hipMemcpyAsync(edge_index_out + base, d_ei + base, (size_t)tot * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
+                HIP_TRY(hipMemcpyAsync(edge_src_global + base, d_es + base, (size_t)tot * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
+            }
+            base += tot;
+        }
+        // row 1 of edge_index: its place in the caller's [2, total] is known now (the last chunk's event orders it behind every fill)
+        if (base > 0) HIP_TRY(hipMemcpyAsync(edge_index_out + base, d_ei + cap, (size_t)base * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipStreamSynchronize(cs));
+        *total_edges_out = base;
+        return UGS_OK;
+    };
+    int rc = body();
+    if (rc != UGS_OK) { if (cs) (void)hipStreamSynchronize(cs); (void)hipStreamSynchronize(s); }   // nothing may still read the pool buffers
+    for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
+    pool_put(d_nodes_b); pool_put(d_eptr_b); pool_put(d_loc_b); pool_put(d_edges_b);
+    plan_unref(plan);
+    return rc;
+}
+
 // ---- epsilon_uniform_sampler.sample_batch (reference src/samplers/epsilon_uniform_sampler/src/epsilon_uniform_sampler.cpp) ----
 int ugs_eps_sample_batch_begin(const int64_t *edge_index, int64_t row_stride, int64_t num_cols, const int64_t *ptr, int64_t num_graphs,
                                int m_per_graph, int k, int mode, uint64_t seed, double epsilon, ugs_job **job_out, int64_t *total_edges_out) {

@@ -13,10 +13,11 @@ Additions that the reference does not have (all optional, keyword-only or separa
     (multi-GPU sharding, see ugs_sampler.distributed).
 """
 import ctypes as C
+import os
 
 import torch
 
-from ._lib import check, lib, vp
+from ._lib import UGS_E_CAPACITY, check, lib, vp
 
 __version__ = (lib.ugs_version() or b"").decode()
 __all__ = ["sample", "create_preproc", "destroy_preproc", "has_graphlets", "get_preproc_info", "sample_batch",
@@ -175,6 +176,41 @@ def sample(handle, m_per_graph, k, edge_mode="local", base_offset=0, seed=42, *,
 # ---------------------------------------------------------------------------------------------------------
 # batch API
 # ---------------------------------------------------------------------------------------------------------
+# Large host-visible calls: a call whose shape (columns, graphs, m, k, mode) was seen before hands its pinned output buffers to the
+# library up front -- the edge buffers sized by the largest total seen for that shape plus 2 % -- and the library copies finished row
+# chunks out while the next ones walk (ugs_sample_batch_stream).  The first call of a shape, and a call that outgrows the estimate,
+# take the two-phase path (walk, allocate by the total, fill, copy).  Same tensors either way.
+_STREAM_MIN_ROWS = 262144
+_stream_totals = {}
+
+
+def _sample_batch_streamed(p, stride, e, ptr_c, G, m, k, mode, seed):
+    key = (e, G, m, k, mode)
+    seen = _stream_totals.get(key)
+    if seen is None or not torch.cuda.is_available():
+        return None
+    cap = seen + seen // 50 + 4096
+    B = G * m
+    opts, _ = _out_opts(None)
+    sizes = [B * k, B + 1, G + 1, cap, 2 * cap]
+    buf = torch.empty((sum(sizes),), **opts)
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + n)
+    base = buf.data_ptr()
+    total = C.c_int64()
+    rc = lib.ugs_sample_batch_stream(p, stride, e, ptr_c.data_ptr(), G, m, k, _BATCH_MODES[mode], seed, cap,
+                                     base + 8 * offs[0], base + 8 * offs[4], base + 8 * offs[1], base + 8 * offs[2], base + 8 * offs[3],
+                                     C.byref(total))
+    if rc == UGS_E_CAPACITY:
+        return None                      # (the two-phase path repeats the call and raises the estimate)
+    check(rc)
+    t = total.value
+    _stream_totals[key] = max(seen, t)
+    return (buf[offs[0]:offs[1]].view(B, k), buf[offs[4]:offs[4] + 2 * t].view(2, t), buf[offs[1]:offs[2]],
+            buf[offs[2]:offs[3]], buf[offs[3]:offs[3] + t])
+
+
 def sample_batch(edge_index, ptr, m_per_graph, k, mode="sample", seed=42, *, device=None):
     """Sample m_per_graph k-subgraphs per graph from a batched PyG edge_index + ptr.
 
@@ -189,8 +225,15 @@ def sample_batch(edge_index, ptr, m_per_graph, k, mode="sample", seed=42, *, dev
     ptr_c = ptr.contiguous()
     G = ptr_c.numel() - 1
     _select_device(device, jobs=True)
+    if device is None and max(G, 0) * m >= _STREAM_MIN_ROWS and not os.environ.get("UGS_NO_STREAMED_CALL"):
+        out = _sample_batch_streamed(p, stride, e, ptr_c, G, m, k, mode, seed)
+        if out is not None:
+            return out
     job, total = vp(), C.c_int64()
     check(lib.ugs_sample_batch_begin(p, stride, e, ptr_c.data_ptr(), G, m, k, _BATCH_MODES[mode], seed, C.byref(job), C.byref(total)))
+    if device is None and max(G, 0) * m >= _STREAM_MIN_ROWS:
+        key = (e, G, m, k, mode)
+        _stream_totals[key] = max(_stream_totals.get(key, 0), total.value)
     try:
         opts, on_dev = _out_opts(device)
         B = max(G, 0) * m

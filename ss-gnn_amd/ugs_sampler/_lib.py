@@ -34,6 +34,8 @@ def _load():
                                    C.POINTER(vp), i64p],
         "ugs_sample_batch_finish": [vp, vp, vp, vp, vp, vp, C.c_int],
         "ugs_job_cancel": [vp],
+        "ugs_sample_batch_stream": [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                    vp, vp, vp, vp, vp, i64p],
         "ugs_apx_sample_batch": [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, C.c_uint64, C.c_double, vp, i64p],
         "ugs_apx_gpu_sample_batch": [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, C.c_uint64, C.c_double, vp, i64p, vp, vp, C.c_int64],
         "ugs_eps_sample_batch_begin": [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_double,
@@ -71,6 +73,7 @@ def _load():
 lib, EXPORTS = _load()
 
 UGS_E_BAD_ARG = -4
+UGS_E_CAPACITY = -9
 
 
 def check(rc):

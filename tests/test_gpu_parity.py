@@ -776,3 +776,74 @@ def test_step_in_one_call_equals_walk_then_fill(fused, monkeypatch):
     nodes, eptr, eidx, esrc = plan.step(500, "global", 9, edge_capacity=tot)
     assert torch.equal(nodes, n2) and torch.equal(eptr, p2) and torch.equal(eidx, e2) and torch.equal(esrc, s2)
     plan.close()
+
+
+def _er(rng, n, deg):
+    e = rng.integers(0, n, size=(2, n * deg // 2), dtype=np.int64)
+    return e[:, e[0] != e[1]]
+
+
+@pytest.mark.parametrize("shape", ["small_graphs", "er_degree_20", "er_degree_90"])
+def test_streamed_call_equals_the_two_phase_call_and_the_oracle(shape, monkeypatch):
+    """ugs_sample_batch_stream (rows in chunks, copy-out beside the walks, row 1 of edge_index last) against the two-phase call of
+    the product and against the CPU oracle: all five tensors, every mode, chunks that cut through graphs, a last chunk of one row,
+    one chunk for everything, the estimate exactly at the total; a call that outgrows its estimate falls back and says so."""
+    import ctypes as C
+    import torch
+    import oracle
+    import ugs_sampler
+    from ugs_sampler._lib import lib, UGS_E_CAPACITY
+    rng = np.random.default_rng(5)
+    if shape == "small_graphs":
+        pr = random.Random(9)
+        ei, ptr = _rand_batch(pr, [5, 9, 17, 30], [0.3, 0.6])
+        while len(ptr) - 1 < 4:
+            ei, ptr = _rand_batch(pr, [5, 9, 17, 30], [0.3, 0.6])
+        m, k = 301, 4
+    elif shape == "er_degree_20":
+        ei, ptr, m, k = _er(rng, 3000, 20), np.array([0, 3000], dtype=np.int64), 2501, 8     # one walk per wave, staged edges
+    else:
+        ei, ptr, m, k = _er(rng, 1500, 90), np.array([0, 1500], dtype=np.int64), 900, 6
+    ei = np.ascontiguousarray(ei)                                   # (_rand_batch hands out a transposed view; the direct calls below pass raw pointers)
+    ei_t, ptr_t = torch.from_numpy(ei), torch.from_numpy(ptr)
+    monkeypatch.setattr(ugs_sampler, "_STREAM_MIN_ROWS", 1)
+    ugs_sampler._stream_totals.clear()
+    cache = oracle.Cache(1000)
+    B = (len(ptr) - 1) * m
+    for mode, chunk in (("sample", 97), ("graph", B - 1), ("global", B + 5), ("sample", 1000)):
+        monkeypatch.setenv("UGS_NO_STREAMED_CALL", "1")
+        two_phase = ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode=mode, seed=7)
+        monkeypatch.delenv("UGS_NO_STREAMED_CALL")
+        monkeypatch.setenv("UGS_STREAM_CHUNK_ROWS", str(chunk))
+        first = ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode=mode, seed=7)          # first call of a shape: two-phase, remembers the total
+        key = (ei.shape[1], len(ptr) - 1, m, k, mode)
+        assert ugs_sampler._stream_totals[key] >= two_phase[1].shape[1]                   # (the largest total seen for the shape)
+        streamed = ugs_sampler._sample_batch_streamed(ei_t.data_ptr(), ei_t.stride(0), ei.shape[1], ptr_t, len(ptr) - 1, m, k, mode, 7)
+        assert streamed is not None
+        other_seed = ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode=mode, seed=8)
+        want = oracle.sample_batch(ei, ptr, m, k, mode, 7, cache=cache)
+        want8 = oracle.sample_batch(ei, ptr, m, k, mode, 8, cache=cache)
+        for name, a, b, c, w, o8, w8 in zip(("nodes", "edge_index", "edge_ptr", "sample_ptr", "edge_src"), two_phase, first, streamed, want, other_seed, want8):
+            assert c.is_contiguous() and c.dtype == torch.int64
+            assert np.array_equal(a.numpy(), np.asarray(w)), (shape, mode, name, "two-phase vs oracle")
+            assert np.array_equal(b.numpy(), np.asarray(w)) and np.array_equal(c.numpy(), np.asarray(w)), (shape, mode, name, "streamed vs oracle")
+            assert np.array_equal(o8.numpy(), np.asarray(w8)), (shape, mode, name, "streamed, other seed vs oracle")
+    # the estimate exactly at the total works; one below it is refused with UGS_E_CAPACITY, and the shim then takes the two-phase path
+    tot = two_phase[1].shape[1]
+    assert tot > 0
+    for cap, expect in ((tot, 0), (tot - 1, UGS_E_CAPACITY)):
+        bufs = [torch.empty(n, dtype=torch.int64).pin_memory() for n in (B * k, 2 * max(cap, 1), B + 1, len(ptr), max(cap, 1))]
+        t = C.c_int64()
+        rc = lib.ugs_sample_batch_stream(ei_t.data_ptr(), ei_t.stride(0), ei.shape[1], ptr_t.data_ptr(), len(ptr) - 1, m, k, 0, 7, cap,
+                                         *[b.data_ptr() for b in bufs], C.byref(t))
+        assert rc == expect, (rc, expect)
+        if rc == 0:
+            assert t.value == tot and np.array_equal(bufs[1][:2 * tot].view(2, tot).numpy(), two_phase[1].numpy())
+    key = (ei.shape[1], len(ptr) - 1, m, k, "sample")
+    ugs_sampler._stream_totals[key] = tot // 2                                           # an estimate far too small
+    again = ugs_sampler.sample_batch(ei_t, ptr_t, m, k, mode="sample", seed=7)
+    assert ugs_sampler._stream_totals[key] == tot                                        # the two-phase path raised it
+    for a, b in zip(again, two_phase):
+        assert np.array_equal(a.numpy(), b.numpy())
+    cache.close()
+    ugs_sampler._stream_totals.clear()
