@@ -114,6 +114,12 @@ int ugs_sample_batch_stream(const int64_t *edge_index, int64_t row_stride, int64
                             int64_t num_graphs, int m_per_graph, int k, int mode, int seed, int64_t edge_capacity,
                             int64_t *nodes, int64_t *edge_index_out, int64_t *edge_ptr, int64_t *sample_ptr,
                             int64_t *edge_src_global, int64_t *total_edges_out);
+/* ugs_sample_batch_stream starts early: a batch whose 32 sampled words (first / last / evenly spaced columns, ptr ends) match a
+ * batch seen before begins its walks on that batch's plan while the real lookup -- the content hash over every column and the LRU
+ * replay of include/cache.hpp:81-109 -- runs on a helper thread; the results stand only if the lookup names the same plan, otherwise
+ * the streams are drained and the call runs again on the right plan (same results, the early work is lost).  Counters since process
+ * start: early starts that stood / that were thrown away.  UGS_NO_SPECULATION set = always look up first. */
+int ugs_stream_stats(int64_t *early_starts_kept, int64_t *early_starts_discarded);
 
 /* LRU of preprocessing handles used by ugs_sample_batch_* (capacity from UGS_CACHE_SIZE, default 1000;
  * reference src/ugs_sampler_batch_extension.cpp:15-38).  Clearing it is the equivalent of a fresh process. */

@@ -840,6 +840,20 @@ struct BatchEntry {
 std::mutex g_bi_mu;
 std::list<BatchEntry> &g_batch_index = *new std::list<BatchEntry>();   // front = most recent, at most as many as cached plans
 void batch_index_clear() { std::lock_guard<std::mutex> lk(g_bi_mu); g_batch_index.clear(); }
+// The plan a batch PROBABLY maps to, from the 32 sampled words alone (no pass over the columns, no LRU effect): the streamed call
+// starts its walks on it while the real lookup -- content hash, LRU replay -- runs, and keeps them only if that lookup names the same plan.
+ugs_plan *peek_batch_plan(const int64_t *src, const int64_t *dst, int64_t E, const int64_t *ptr, int64_t G, int k, int dev) {
+    const Witness wit = batch_witness(src, dst, E, ptr, G);
+    uint64_t key = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_bi_mu);
+        auto it = g_batch_index.begin();
+        for (; it != g_batch_index.end(); ++it)
+            if (it->E == E && it->G == G && it->k == k && it->dev == dev && it->wit == wit) { key = it->plan_key; break; }
+        if (it == g_batch_index.end()) return nullptr;
+    }
+    return plan_cache_get(key, dev);
+}
 
 // A long array is hashed in chunks of a FIXED size (the value must not depend on the number of threads) by a few helper
 // threads; the chunk hashes are then hashed in order.  (20M columns: the hashing pass drops from ~10 ms to ~2 ms of a 20 ms call.)
@@ -2419,6 +2433,7 @@ int ugs_job_cancel(ugs_job *job) { free_job(job); return UGS_OK; }
 // the job stream, and every finished chunk leaves on a second stream while the next one walks.  Row 1 of edge_index [2, total] starts
 // at `total`, known with the last chunk only: that half is kept in the device staging and leaves at the end.
 namespace {
+std::atomic<int64_t> g_spec_kept{0}, g_spec_wrong{0};              // streamed calls whose early start stood / was thrown away
 std::mutex g_copy_mu;
 std::map<int, hipStream_t> &g_copy_streams = *new std::map<int, hipStream_t>();
 int copy_stream(int dev, hipStream_t &out) {
@@ -2434,6 +2449,12 @@ int copy_stream(int dev, hipStream_t &out) {
 }
 }  // namespace
 
+int ugs_stream_stats(int64_t *early_starts_kept, int64_t *early_starts_discarded) {
+    if (early_starts_kept) *early_starts_kept = g_spec_kept.load();
+    if (early_starts_discarded) *early_starts_discarded = g_spec_wrong.load();
+    return UGS_OK;
+}
+
 int ugs_sample_batch_stream(const int64_t *edge_index, int64_t row_stride, int64_t num_cols, const int64_t *ptr, int64_t num_graphs,
                             int m_per_graph, int k, int mode, int seed, int64_t edge_capacity, int64_t *nodes, int64_t *edge_index_out,
                             int64_t *edge_ptr, int64_t *sample_ptr, int64_t *edge_src_global, int64_t *total_edges_out) {
@@ -2442,12 +2463,28 @@ int ugs_sample_batch_stream(const int64_t *edge_index, int64_t row_stride, int64
     if (k < 1) return fail(UGS_E_BAD_ARG, "k must be >= 1");
     if (k > UGS_KMAX) return fail(UGS_E_UNSUPPORTED, "k > 32 is not supported by the HIP sampler");
     if (edge_capacity < 0 || !edge_ptr || !total_edges_out) return fail(UGS_E_BAD_ARG, "null output pointer or negative edge_capacity");
-    ugs_plan *plan = nullptr;
-    if (int rc = ugs_plan_create_batch(edge_index, row_stride, num_cols, ptr, num_graphs, k, &plan)) return rc;
+    if (!ptr || num_graphs < 0 || num_cols < 0 || (num_cols > 0 && !edge_index)) return fail(UGS_E_BAD_ARG, "bad arguments to sample_batch");
     DeviceCtx dc;
-    if (int rc = device_ctx(dc)) { plan_unref(plan); return rc; }
-    const int64_t G = plan->G, rows = G * (int64_t)m_per_graph, cap = edge_capacity;
-    if (rows > 0 && (!nodes || (cap > 0 && (!edge_index_out || !edge_src_global)))) { plan_unref(plan); return fail(UGS_E_BAD_ARG, "null output pointer"); }
+    if (int rc = device_ctx(dc)) return rc;
+    const int64_t G = num_graphs, rows = G * (int64_t)m_per_graph, cap = edge_capacity;
+    if (rows > 0 && (!nodes || (cap > 0 && (!edge_index_out || !edge_src_global)))) return fail(UGS_E_BAD_ARG, "null output pointer");
+    // The real lookup reads every column (content hash: ~3 ms for 20 M columns).  A batch whose sampled words match a remembered one
+    // starts on that batch's plan at once, the lookup runs beside it on a helper thread, and the results stand only if the lookup
+    // returns the same plan; otherwise the streams are drained and the call runs again on the right one.
+    ugs_plan *plan = nullptr, *guess = nullptr;
+    if (rows > 0 && !debug_on() && std::getenv("UGS_NO_SPECULATION") == nullptr && std::getenv("UGS_NO_BATCH_INDEX") == nullptr)
+        guess = peek_batch_plan(edge_index, edge_index + row_stride, num_cols, ptr, G, k, dc.id);
+    std::thread lookup_thread;
+    int lookup_rc = UGS_OK;
+    std::string lookup_err;
+    if (guess) {
+        const int dev_tl = t_device; const hipStream_t st_tl = t_job_stream; const bool set_tl = t_job_stream_set;
+        lookup_thread = std::thread([&, dev_tl, st_tl, set_tl] {
+            t_device = dev_tl >= 0 ? dev_tl : dc.id; t_job_stream = st_tl; t_job_stream_set = set_tl;
+            lookup_rc = ugs_plan_create_batch(edge_index, row_stride, num_cols, ptr, num_graphs, k, &plan);
+            if (lookup_rc != UGS_OK) lookup_err = t_err;
+        });
+    } else if (int rc = ugs_plan_create_batch(edge_index, row_stride, num_cols, ptr, num_graphs, k, &plan)) return rc;
     int64_t chunk = (rows + 7) / 8;                                   // eight chunks: the first copy starts after an eighth of the walks
     if (chunk < 65536) chunk = 65536;
     if (const char *e = std::getenv("UGS_STREAM_CHUNK_ROWS")) { const int64_t v = std::atoll(e); if (v > 0) chunk = v; }   // (tests: many chunks of a small call)
@@ -2456,15 +2493,16 @@ int ugs_sample_batch_stream(const int64_t *edge_index, int64_t row_stride, int64
     PoolBuf d_nodes_b, d_eptr_b, d_loc_b, d_edges_b;
     std::vector<hipEvent_t> evs;
     int64_t base = 0;
-    auto body = [&]() -> int {
+    auto body = [&](ugs_plan *plan) -> int {
+        base = 0;
         HIP_TRY(hipSetDevice(dc.id));
         if (int rc = copy_stream(dc.id, cs)) return rc;
         if (sample_ptr) for (int64_t g = 0; g <= G; ++g) sample_ptr[g] = g * (int64_t)m_per_graph;
         if (rows == 0) { edge_ptr[0] = 0; *total_edges_out = 0; return UGS_OK; }
-        if (int rc = pool_get((size_t)(rows * k) * sizeof(int64_t), dc.id, d_nodes_b)) return rc;
-        if (int rc = pool_get((size_t)(rows + 1) * sizeof(int64_t), dc.id, d_eptr_b)) return rc;
-        if (int rc = pool_get((size_t)(chunk + 1) * sizeof(int64_t), dc.id, d_loc_b)) return rc;
-        if (cap > 0) if (int rc = pool_get((size_t)(3 * cap) * sizeof(int64_t), dc.id, d_edges_b)) return rc;
+        if (!d_nodes_b.p) if (int rc = pool_get((size_t)(rows * k) * sizeof(int64_t), dc.id, d_nodes_b)) return rc;
+        if (!d_eptr_b.p) if (int rc = pool_get((size_t)(rows + 1) * sizeof(int64_t), dc.id, d_eptr_b)) return rc;
+        if (!d_loc_b.p) if (int rc = pool_get((size_t)(chunk + 1) * sizeof(int64_t), dc.id, d_loc_b)) return rc;
+        if (cap > 0 && !d_edges_b.p) if (int rc = pool_get((size_t)(3 * cap) * sizeof(int64_t), dc.id, d_edges_b)) return rc;
         int64_t *d_nodes = static_cast<int64_t *>(d_nodes_b.p), *d_eptr = static_cast<int64_t *>(d_eptr_b.p), *d_loc = static_cast<int64_t *>(d_loc_b.p);
         int64_t *d_ei = static_cast<int64_t *>(d_edges_b.p), *d_es = d_ei ? d_ei + 2 * cap : nullptr;
         for (int64_t c = 0; c < nchunks; ++c) {
@@ -2495,11 +2533,23 @@ int ugs_sample_batch_stream(const int64_t *edge_index, int64_t row_stride, int64
         *total_edges_out = base;
         return UGS_OK;
     };
-    int rc = body();
-    if (rc != UGS_OK) { if (cs) (void)hipStreamSynchronize(cs); (void)hipStreamSynchronize(s); }   // nothing may still read the pool buffers
+    auto drain = [&] { if (cs) (void)hipStreamSynchronize(cs); (void)hipStreamSynchronize(s); };
+    int rc = UGS_OK;
+    if (guess) {
+        std::string guess_err;
+        rc = body(guess);
+        if (rc != UGS_OK) guess_err = t_err;
+        lookup_thread.join();
+        if (lookup_rc != UGS_OK) { drain(); rc = fail(lookup_rc, lookup_err); }             // the call's own error (what the two-phase call reports)
+        else if (plan != guess) { drain(); g_spec_wrong.fetch_add(1); rc = body(plan); }      // a different batch after all: once more, on its plan
+        else if (rc != UGS_OK) rc = fail(rc, guess_err);
+        else g_spec_kept.fetch_add(1);
+        plan_unref(guess);
+    } else rc = body(plan);
+    if (rc != UGS_OK) drain();                                      // nothing may still read the pool buffers
     for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
     pool_put(d_nodes_b); pool_put(d_eptr_b); pool_put(d_loc_b); pool_put(d_edges_b);
-    plan_unref(plan);
+    if (plan) plan_unref(plan);
     return rc;
 }
 
