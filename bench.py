@@ -674,7 +674,8 @@ def bench_drop_in(name, ugs_sampler, ei_t, ptr_t, m, k, mode, dev, reps):
             "device_out_ms": round(dt_dev * 1e3, 3), "device_out_subgraphs_per_s": round(rows / dt_dev, 1), "reps": reps,
             "host_visible_streamed": bool(streamed), "host_visible_two_phase_ms": two_phase_ms,
             "note": "host tensors in every call (the reference's interface): per call the library hashes the batch's bytes (a batch seen before is matched as "
-                    "a whole; the per-graph LRU is touched as the general path would), samples, and copies out"}
+                    "a whole; the per-graph LRU is touched as the general path would), samples, and copies out; calls of >= 262144 rows are streamed "
+                    "(row chunks copied out beside the walks, walks begun while the hash runs: ugs_sample_batch_stream)"}
 
 
 def small_traffic(name):

@@ -118,7 +118,8 @@ int ugs_sample_batch_stream(const int64_t *edge_index, int64_t row_stride, int64
  * batch seen before begins its walks on that batch's plan while the real lookup -- the content hash over every column and the LRU
  * replay of include/cache.hpp:81-109 -- runs on a helper thread; the results stand only if the lookup names the same plan, otherwise
  * the streams are drained and the call runs again on the right plan (same results, the early work is lost).  Counters since process
- * start: early starts that stood / that were thrown away.  UGS_NO_SPECULATION set = always look up first. */
+ * start: early starts that stood / that were thrown away.  UGS_NO_SPECULATION set = always look up first.  ugs_sample_batch_begin does
+ * the same for batches of >= 2^21 columns (UGS_SPEC_MIN_COLS overrides the threshold: testing aid) and counts here too. */
 int ugs_stream_stats(int64_t *early_starts_kept, int64_t *early_starts_discarded);
 
 /* LRU of preprocessing handles used by ugs_sample_batch_* (capacity from UGS_CACHE_SIZE, default 1000;

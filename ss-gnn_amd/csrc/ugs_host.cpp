@@ -2238,6 +2238,7 @@ struct ugs_job {
 };
 
 namespace {
+std::atomic<int64_t> g_spec_kept{0}, g_spec_wrong{0};              // large calls whose early start stood / was thrown away
 void free_job(ugs_job *j) {
     if (!j) return;
     pool_put(j->nodes);
@@ -2414,6 +2415,32 @@ int ugs_sample_batch_begin(const int64_t *edge_index, int64_t row_stride, int64_
     if (k < 1) return fail(UGS_E_BAD_ARG, "k must be >= 1");
     if (k > UGS_KMAX) return fail(UGS_E_UNSUPPORTED, "k > 32 is not supported by the HIP sampler");
     ugs_plan *plan = nullptr;
+    // Large batches start early, like ugs_sample_batch_stream below: the walks begin on the plan the batch's sampled words point at while
+    // the lookup (content hash over every column: ~3 ms for 20 M columns) runs on a helper thread; kept only if it names the same plan.
+    ugs_plan *guess = nullptr;
+    DeviceCtx dc;
+    const int64_t spec_min_cols = [] { const char *e = std::getenv("UGS_SPEC_MIN_COLS"); return e ? (int64_t)std::atoll(e) : (int64_t)1 << 21; }();   // (tests lower it)
+    if (num_cols >= spec_min_cols && ptr && edge_index && num_graphs > 0 && m_per_graph > 0 && !debug_on() &&
+        std::getenv("UGS_NO_SPECULATION") == nullptr && std::getenv("UGS_NO_BATCH_INDEX") == nullptr && device_ctx(dc) == UGS_OK)
+        guess = peek_batch_plan(edge_index, edge_index + row_stride, num_cols, ptr, num_graphs, k, dc.id);
+    if (guess) {
+        int lookup_rc = UGS_OK;
+        std::string lookup_err;
+        const int dev_tl = t_device; const hipStream_t st_tl = t_job_stream; const bool set_tl = t_job_stream_set;
+        std::thread lookup_thread([&, dev_tl, st_tl, set_tl] {
+            t_device = dev_tl >= 0 ? dev_tl : dc.id; t_job_stream = st_tl; t_job_stream_set = set_tl;
+            lookup_rc = ugs_plan_create_batch(edge_index, row_stride, num_cols, ptr, num_graphs, k, &plan);
+            if (lookup_rc != UGS_OK) lookup_err = t_err;
+        });
+        *job_out = nullptr;
+        const int rc = begin_common(guess, m_per_graph, k, mode, 0, seed, true, job_out, total_edges_out);   // (owns the guess's reference)
+        lookup_thread.join();
+        if (lookup_rc != UGS_OK) { if (rc == UGS_OK) { free_job(*job_out); *job_out = nullptr; } return fail(lookup_rc, lookup_err); }
+        if (plan == guess) { plan_unref(plan); g_spec_kept.fetch_add(1); return rc; }
+        if (rc == UGS_OK) { free_job(*job_out); *job_out = nullptr; }                       // a different batch after all: once more, on its plan
+        g_spec_wrong.fetch_add(1);
+        return begin_common(plan, m_per_graph, k, mode, 0, seed, true, job_out, total_edges_out);
+    }
     if (int rc = ugs_plan_create_batch(edge_index, row_stride, num_cols, ptr, num_graphs, k, &plan)) return rc;
     return begin_common(plan, m_per_graph, k, mode, 0, seed, true, job_out, total_edges_out);
 }
@@ -2433,7 +2460,6 @@ int ugs_job_cancel(ugs_job *job) { free_job(job); return UGS_OK; }
 // the job stream, and every finished chunk leaves on a second stream while the next one walks.  Row 1 of edge_index [2, total] starts
 // at `total`, known with the last chunk only: that half is kept in the device staging and leaves at the end.
 namespace {
-std::atomic<int64_t> g_spec_kept{0}, g_spec_wrong{0};              // streamed calls whose early start stood / was thrown away
 std::mutex g_copy_mu;
 std::map<int, hipStream_t> &g_copy_streams = *new std::map<int, hipStream_t>();
 int copy_stream(int dev, hipStream_t &out) {

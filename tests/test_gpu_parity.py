@@ -860,6 +860,21 @@ def test_streamed_call_equals_the_two_phase_call_and_the_oracle(shape, monkeypat
     for a, b in zip(got, two_phase):
         assert np.array_equal(a.numpy(), b.numpy())
     monkeypatch.delenv("UGS_NO_SPECULATION")
+    # the two-phase call starts early too for large batches (threshold lowered here): a kept start, a thrown-away one, host and device outputs
+    monkeypatch.setenv("UGS_NO_STREAMED_CALL", "1")
+    monkeypatch.setenv("UGS_SPEC_MIN_COLS", "1")
+    ei3 = ei.copy()
+    ei3[:, c] = ei3[:, c + 1] if c + 1 not in sampled else ei3[:, c - 2]
+    k_a, w_a = stats()
+    for dev in (None, "cuda:0"):
+        for arr, seed in ((ei, 11), (ei3, 11), (ei3, 12)):
+            got = ugs_sampler.sample_batch(torch.from_numpy(arr), ptr_t, m, k, mode="graph", seed=seed, device=dev)
+            for a, w in zip(got, oracle.sample_batch(arr, ptr, m, k, "graph", seed, cache=cache)):
+                assert np.array_equal(a.cpu().numpy(), np.asarray(w))
+    k_b, w_b = stats()
+    assert k_b + w_b == k_a + w_a + 6 and k_b >= k_a + 3 and (shape != "small_graphs" or w_b >= w_a + 2)
+    monkeypatch.delenv("UGS_SPEC_MIN_COLS")
+    monkeypatch.delenv("UGS_NO_STREAMED_CALL")
     # the estimate exactly at the total works; one below it is refused with UGS_E_CAPACITY, and the shim then takes the two-phase path
     tot = two_phase[1].shape[1]
     assert tot > 0
