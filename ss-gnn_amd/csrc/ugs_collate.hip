@@ -117,32 +117,3 @@ hipError_t ugs_launch_rebase_edge_ptr(const int64_t *in, int64_t *out, int64_t n
     hipLaunchKernelGGL(ugs_rebase_edge_ptr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n, base);
     return hipGetLastError();
 }
-
-// ---- copy-out beside a walk launch (ugs_sample_batch_stream) ---------------------------------------------------------------------
-// The runtime's own device-to-host copy is a kernel of 1024-thread groups (16 waves that must find room on one CU together): beside the
-// persistent walk grid -- 5 waves of 88 VGPRs per SIMD, resident until the launch ends -- those groups wait, the copy of a chunk takes as
-// long as the next chunk's walk, and PCIe idles meanwhile (profiles/r04_streamed_call_overlap.txt).  This one is made of single waves
-// with a handful of registers, which fit into the slots the walk leaves free: up to four segments per launch, 8-byte elements (the
-// segments start at arbitrary int64 offsets), eight independent loads in flight per lane, then eight stores to the pinned destination.
-namespace {
-__global__ __launch_bounds__(64) void ugs_copy_out(UgsCopySegs a) {
-    const int seg = blockIdx.y;
-    const int64_t n = a.n[seg];
-    const int64_t *__restrict__ src = a.src[seg];
-    int64_t *__restrict__ dst = a.dst[seg];
-    const int64_t stride = (int64_t)gridDim.x * 512;
-    for (int64_t i0 = (int64_t)blockIdx.x * 512 + threadIdx.x; i0 < n; i0 += stride) {
-        int64_t v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int64_t i = i0 + u * 64; v[u] = i < n ? __builtin_nontemporal_load(src + i) : 0; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int64_t i = i0 + u * 64; if (i < n) dst[i] = v[u]; }
-    }
-}
-}  // namespace
-
-hipError_t ugs_launch_copy_out(const UgsCopySegs &a, int segs, int blocks, hipStream_t s) {
-    if (segs <= 0) return hipSuccess;
-    hipLaunchKernelGGL(ugs_copy_out, dim3((unsigned)blocks, (unsigned)segs), dim3(64), 0, s, a);
-    return hipGetLastError();
-}

@@ -161,9 +161,6 @@ hipError_t ugs_launch_collate_unpack(const void *d_msgs, int world, int64_t msg_
                                      hipStream_t s);
 // out[i] = in[i] + base, i < n (a row chunk's edge_ptr moved to its place in the whole call's: ugs_sample_batch_stream)
 hipError_t ugs_launch_rebase_edge_ptr(const int64_t *in, int64_t *out, int64_t n, int64_t base, hipStream_t s);
-// up to four (src, dst, n int64 elements) segments copied by one launch of single-wave groups (dst: pinned host memory; ugs_collate.hip)
-struct UgsCopySegs { const int64_t *src[4]; int64_t *dst[4]; int64_t n[4]; };
-hipError_t ugs_launch_copy_out(const UgsCopySegs &a, int segs, int blocks, hipStream_t s);
 // device batch pass (ugs_batch.hip): slicing, LRU keys and CSR of a batch of small graphs; limits per graph of that path
 #define UGS_BATCH_PASS_MAX_COLS 1000   /* a key covers every column up to here (reference include/cache.hpp:100 samples longer graphs) */
 #define UGS_BATCH_PASS_MAX_N 2048

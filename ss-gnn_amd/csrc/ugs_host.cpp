@@ -2516,18 +2516,6 @@ int ugs_sample_batch_stream(const int64_t *edge_index, int64_t row_stride, int64
     if (const char *e = std::getenv("UGS_STREAM_CHUNK_ROWS")) { const int64_t v = std::atoll(e); if (v > 0) chunk = v; }   // (tests: many chunks of a small call)
     const int64_t nchunks = rows > 0 ? (rows + chunk - 1) / chunk : 0;
     hipStream_t s = dc.stream, cs = nullptr;
-    // chunk copies: the runtime's copy, or (UGS_STREAM_COPY=kernel) the library's kernel of single waves; the destination must then be
-    // memory the device can address (pinned host memory), which the caller vouches for by asking
-    const char *copy_env = std::getenv("UGS_STREAM_COPY");
-    bool copy_kernel = copy_env && std::strcmp(copy_env, "kernel") == 0;
-    if (copy_kernel) {                                                // every destination must be pinned host memory (or the copy goes the runtime's way)
-        for (const void *q : {(const void *)nodes, (const void *)edge_ptr, (const void *)edge_index_out, (const void *)edge_src_global}) {
-            hipPointerAttribute_t at{};
-            if (!q) continue;
-            if (hipPointerGetAttributes(&at, q) != hipSuccess || at.type != hipMemoryTypeHost) { copy_kernel = false; (void)hipGetLastError(); break; }
-        }
-    }
-    const int copy_blocks = [] { const char *e = std::getenv("UGS_STREAM_COPY_BLOCKS"); const int v = e ? std::atoi(e) : 0; return v > 0 && v <= 65535 ? v : 512; }();
     PoolBuf d_nodes_b, d_eptr_b, d_loc_b, d_edges_b;
     std::vector<hipEvent_t> evs;
     int64_t base = 0;
@@ -2557,22 +2545,11 @@ int ugs_sample_batch_stream(const int64_t *edge_index, int64_t row_stride, int64
             evs.push_back(ev);
             HIP_TRY(hipEventRecord(ev, s));
             HIP_TRY(hipStreamWaitEvent(cs, ev, 0));
-            if (copy_kernel) {          // one launch of single-wave groups that fit beside the next chunk's walk (ugs_collate.hip: ugs_copy_out)
-                UgsCopySegs cp{};
-                cp.src[0] = d_nodes + r0 * k; cp.dst[0] = nodes + r0 * k; cp.n[0] = rc_rows * k;
-                cp.src[1] = d_eptr + r0; cp.dst[1] = edge_ptr + r0; cp.n[1] = rc_rows + (last ? 1 : 0);
-                if (tot > 0) {
-                    cp.src[2] = d_ei + base; cp.dst[2] = edge_index_out + base; cp.n[2] = tot;
-                    cp.src[3] = d_es + base; cp.dst[3] = edge_src_global + base; cp.n[3] = tot;
-                }
-                HIP_TRY(ugs_launch_copy_out(cp, tot > 0 ? 4 : 2, copy_blocks, cs));
-            } else {
             HIP_TRY(hipMemcpyAsync(nodes + r0 * k, d_nodes + r0 * k, (size_t)(rc_rows * k) * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
             HIP_TRY(hipMemcpyAsync(edge_ptr + r0, d_eptr + r0, (size_t)(rc_rows + (last ? 1 : 0)) * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
             if (tot > 0) {
                 HIP_TRY(hipMemcpyAsync(edge_index_out + base, d_ei + base, (size_t)tot * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
                 HIP_TRY(hipMemcpyAsync(edge_src_global + base, d_es + base, (size_t)tot * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
-            }
             }
             base += tot;
         }

@@ -47,22 +47,6 @@ for chunk in ((0,) if os.environ.get("UGS_PROBE_ONLY_DEFAULT") else (0, 31250, 6
     ugs_sampler.sample_batch(ei_t, ptr_t, m, k, seed=41)
     out["streamed"]["default(rows/8)" if not chunk else str(chunk)] = timed()
 os.environ.pop("UGS_STREAM_CHUNK_ROWS", None)
-if not os.environ.get("UGS_PROBE_ONLY_DEFAULT"):      # chunk copies by the library's kernel of single waves instead of the runtime's copy
-    want = ugs_sampler.sample_batch(ei_t, ptr_t, m, k, seed=42)
-    os.environ["UGS_STREAM_COPY"] = "kernel"
-    got = ugs_sampler.sample_batch(ei_t, ptr_t, m, k, seed=42)
-    out["copy_kernel_equals_runtime_copy"] = all(torch.equal(a, b) for a, b in zip(got, want))
-    del got, want
-    for blocks in (128, 256, 512, 1024, 2048):
-        os.environ["UGS_STREAM_COPY_BLOCKS"] = str(blocks)
-        for chunk in (0, 62500):
-            if chunk:
-                os.environ["UGS_STREAM_CHUNK_ROWS"] = str(chunk)
-            ugs_sampler.sample_batch(ei_t, ptr_t, m, k, seed=41)
-            out["streamed"][f"copy kernel, {blocks} waves per segment, " + ("rows/8" if not chunk else f"{chunk} rows per chunk")] = timed()
-            os.environ.pop("UGS_STREAM_CHUNK_ROWS", None)
-    os.environ.pop("UGS_STREAM_COPY_BLOCKS", None)
-    os.environ.pop("UGS_STREAM_COPY", None)
 for d in out["streamed"].values():
     d["subgraphs_per_s"] = round(rows / d["median_ms"] * 1e3, 1)
 out["two_phase"]["subgraphs_per_s"] = round(rows / out["two_phase"]["median_ms"] * 1e3, 1)
