@@ -114,6 +114,11 @@ int ugs_sample_batch_stream(const int64_t *edge_index, int64_t row_stride, int64
                             int64_t num_graphs, int m_per_graph, int k, int mode, int seed, int64_t edge_capacity,
                             int64_t *nodes, int64_t *edge_index_out, int64_t *edge_ptr, int64_t *sample_ptr,
                             int64_t *edge_src_global, int64_t *total_edges_out);
+/* sample() of the handle API (reference src/sampler.cpp:91-290) streamed the same way: nodes[m,k], edge_ptr[m+1],
+ * edge_src[edge_capacity], edge_index_out[2*edge_capacity] (holds [2, total] contiguously on return); UGS_E_CAPACITY as above. */
+int ugs_sample_stream(int64_t handle, int m_per_graph, int k, int edge_mode, int64_t base_offset, int seed,
+                      int64_t edge_capacity, int64_t *nodes, int64_t *edge_index_out, int64_t *edge_ptr, int64_t *edge_src,
+                      int64_t *total_edges_out);
 /* ugs_sample_batch_stream starts early: a batch whose 32 sampled words (first / last / evenly spaced columns, ptr ends) match a
  * batch seen before begins its walks on that batch's plan while the real lookup -- the content hash over every column and the LRU
  * replay of include/cache.hpp:81-109 -- runs on a helper thread; the results stand only if the lookup names the same plan, otherwise

@@ -2473,6 +2473,71 @@ int copy_stream(int dev, hipStream_t &out) {
     out = it->second;
     return UGS_OK;
 }
+
+// One streamed call: parameters, the caller's (pinned host) buffers, and the device staging that outlives a thrown-away early start.
+struct StreamCall {
+    DeviceCtx dc;
+    int64_t G = 0, extra = 0, cap = 0;
+    int m = 0, k = 0, mode = 0, seed = 0;
+    int64_t *nodes = nullptr, *edge_index = nullptr, *edge_ptr = nullptr, *sample_ptr = nullptr, *edge_src = nullptr, *total_out = nullptr;
+    hipStream_t cs = nullptr;
+    PoolBuf d_nodes_b, d_eptr_b, d_loc_b, d_edges_b;
+    std::vector<hipEvent_t> evs;
+    void release() {
+        for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
+        evs.clear();
+        pool_put(d_nodes_b); pool_put(d_eptr_b); pool_put(d_loc_b); pool_put(d_edges_b);
+    }
+};
+
+int stream_rows(ugs_plan *plan, StreamCall &c) {
+    const int64_t rows = c.G * (int64_t)c.m, cap = c.cap;
+    const int k = c.k;
+    int64_t chunk = (rows + 7) / 8;                                   // eight chunks: the first copy starts after an eighth of the walks
+    if (chunk < 65536) chunk = 65536;
+    if (const char *e = std::getenv("UGS_STREAM_CHUNK_ROWS")) { const int64_t v = std::atoll(e); if (v > 0) chunk = v; }   // (tests: many chunks of a small call)
+    const int64_t nchunks = rows > 0 ? (rows + chunk - 1) / chunk : 0;
+    hipStream_t s = c.dc.stream;
+    int64_t base = 0;
+    HIP_TRY(hipSetDevice(c.dc.id));
+    if (int rc = copy_stream(c.dc.id, c.cs)) return rc;
+    hipStream_t cs = c.cs;
+    if (c.sample_ptr) for (int64_t g = 0; g <= c.G; ++g) c.sample_ptr[g] = g * (int64_t)c.m;
+    if (rows == 0) { c.edge_ptr[0] = 0; *c.total_out = 0; return UGS_OK; }
+    if (!c.d_nodes_b.p) if (int rc = pool_get((size_t)(rows * k) * sizeof(int64_t), c.dc.id, c.d_nodes_b)) return rc;
+    if (!c.d_eptr_b.p) if (int rc = pool_get((size_t)(rows + 1) * sizeof(int64_t), c.dc.id, c.d_eptr_b)) return rc;
+    if (!c.d_loc_b.p) if (int rc = pool_get((size_t)(chunk + 1) * sizeof(int64_t), c.dc.id, c.d_loc_b)) return rc;
+    if (cap > 0 && !c.d_edges_b.p) if (int rc = pool_get((size_t)(3 * cap) * sizeof(int64_t), c.dc.id, c.d_edges_b)) return rc;
+    int64_t *d_nodes = static_cast<int64_t *>(c.d_nodes_b.p), *d_eptr = static_cast<int64_t *>(c.d_eptr_b.p), *d_loc = static_cast<int64_t *>(c.d_loc_b.p);
+    int64_t *d_ei = static_cast<int64_t *>(c.d_edges_b.p), *d_es = d_ei ? d_ei + 2 * cap : nullptr;
+    for (int64_t ch = 0; ch < nchunks; ++ch) {
+        const int64_t r0 = ch * chunk, rc_rows = std::min(chunk, rows - r0);
+        const bool last = ch + 1 == nchunks;
+        int64_t tot = 0;
+        if (int rc = plan_walk_impl(plan, c.m, k, c.mode, c.extra, c.seed, nullptr, r0, rc_rows, s, d_nodes + r0 * k, d_loc, &tot, nullptr, true)) return rc;
+        if (base + tot > cap) { *c.total_out = base + tot; return fail(UGS_E_CAPACITY, "edge_capacity too small for this call's edge entries"); }
+        if (tot > 0)
+            if (int rc = ugs_plan_fill(plan, c.m, k, c.mode, c.extra, r0, rc_rows, s, d_nodes + r0 * k, d_loc, d_ei + base, cap, d_es + base)) return rc;
+        HIP_TRY(ugs_launch_rebase_edge_ptr(d_loc, d_eptr + r0, rc_rows + (last ? 1 : 0), base, s));
+        hipEvent_t ev = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        c.evs.push_back(ev);
+        HIP_TRY(hipEventRecord(ev, s));
+        HIP_TRY(hipStreamWaitEvent(cs, ev, 0));
+        HIP_TRY(hipMemcpyAsync(c.nodes + r0 * k, d_nodes + r0 * k, (size_t)(rc_rows * k) * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipMemcpyAsync(c.edge_ptr + r0, d_eptr + r0, (size_t)(rc_rows + (last ? 1 : 0)) * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
+        if (tot > 0) {
+            HIP_TRY(hipMemcpyAsync(c.edge_index + base, d_ei + base, (size_t)tot * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
+            HIP_TRY(hipMemcpyAsync(c.edge_src + base, d_es + base, (size_t)tot * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
+        }
+        base += tot;
+    }
+    // row 1 of edge_index: its place in the caller's [2, total] is known now (the last chunk's event orders it behind every fill)
+    if (base > 0) HIP_TRY(hipMemcpyAsync(c.edge_index + base, d_ei + cap, (size_t)base * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
+    HIP_TRY(hipStreamSynchronize(cs));
+    *c.total_out = base;
+    return UGS_OK;
+}
 }  // namespace
 
 int ugs_stream_stats(int64_t *early_starts_kept, int64_t *early_starts_discarded) {
@@ -2511,55 +2576,13 @@ int ugs_sample_batch_stream(const int64_t *edge_index, int64_t row_stride, int64
             if (lookup_rc != UGS_OK) lookup_err = t_err;
         });
     } else if (int rc = ugs_plan_create_batch(edge_index, row_stride, num_cols, ptr, num_graphs, k, &plan)) return rc;
-    int64_t chunk = (rows + 7) / 8;                                   // eight chunks: the first copy starts after an eighth of the walks
-    if (chunk < 65536) chunk = 65536;
-    if (const char *e = std::getenv("UGS_STREAM_CHUNK_ROWS")) { const int64_t v = std::atoll(e); if (v > 0) chunk = v; }   // (tests: many chunks of a small call)
-    const int64_t nchunks = rows > 0 ? (rows + chunk - 1) / chunk : 0;
-    hipStream_t s = dc.stream, cs = nullptr;
-    PoolBuf d_nodes_b, d_eptr_b, d_loc_b, d_edges_b;
-    std::vector<hipEvent_t> evs;
-    int64_t base = 0;
-    auto body = [&](ugs_plan *plan) -> int {
-        base = 0;
-        HIP_TRY(hipSetDevice(dc.id));
-        if (int rc = copy_stream(dc.id, cs)) return rc;
-        if (sample_ptr) for (int64_t g = 0; g <= G; ++g) sample_ptr[g] = g * (int64_t)m_per_graph;
-        if (rows == 0) { edge_ptr[0] = 0; *total_edges_out = 0; return UGS_OK; }
-        if (!d_nodes_b.p) if (int rc = pool_get((size_t)(rows * k) * sizeof(int64_t), dc.id, d_nodes_b)) return rc;
-        if (!d_eptr_b.p) if (int rc = pool_get((size_t)(rows + 1) * sizeof(int64_t), dc.id, d_eptr_b)) return rc;
-        if (!d_loc_b.p) if (int rc = pool_get((size_t)(chunk + 1) * sizeof(int64_t), dc.id, d_loc_b)) return rc;
-        if (cap > 0 && !d_edges_b.p) if (int rc = pool_get((size_t)(3 * cap) * sizeof(int64_t), dc.id, d_edges_b)) return rc;
-        int64_t *d_nodes = static_cast<int64_t *>(d_nodes_b.p), *d_eptr = static_cast<int64_t *>(d_eptr_b.p), *d_loc = static_cast<int64_t *>(d_loc_b.p);
-        int64_t *d_ei = static_cast<int64_t *>(d_edges_b.p), *d_es = d_ei ? d_ei + 2 * cap : nullptr;
-        for (int64_t c = 0; c < nchunks; ++c) {
-            const int64_t r0 = c * chunk, rc_rows = std::min(chunk, rows - r0);
-            const bool last = c + 1 == nchunks;
-            int64_t tot = 0;
-            if (int rc = plan_walk_impl(plan, m_per_graph, k, mode, 0, seed, nullptr, r0, rc_rows, s, d_nodes + r0 * k, d_loc, &tot, nullptr, true)) return rc;
-            if (base + tot > cap) { *total_edges_out = base + tot; return fail(UGS_E_CAPACITY, "edge_capacity too small for this call's edge entries"); }
-            if (tot > 0)
-                if (int rc = ugs_plan_fill(plan, m_per_graph, k, mode, 0, r0, rc_rows, s, d_nodes + r0 * k, d_loc, d_ei + base, cap, d_es + base)) return rc;
-            HIP_TRY(ugs_launch_rebase_edge_ptr(d_loc, d_eptr + r0, rc_rows + (last ? 1 : 0), base, s));
-            hipEvent_t ev = nullptr;
-            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            evs.push_back(ev);
-            HIP_TRY(hipEventRecord(ev, s));
-            HIP_TRY(hipStreamWaitEvent(cs, ev, 0));
-            HIP_TRY(hipMemcpyAsync(nodes + r0 * k, d_nodes + r0 * k, (size_t)(rc_rows * k) * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
-            HIP_TRY(hipMemcpyAsync(edge_ptr + r0, d_eptr + r0, (size_t)(rc_rows + (last ? 1 : 0)) * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
-            if (tot > 0) {
-                HIP_TRY(hipMemcpyAsync(edge_index_out + base, d_ei + base, (size_t)tot * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
-                HIP_TRY(hipMemcpyAsync(edge_src_global + base, d_es + base, (size_t)tot * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
-            }
-            base += tot;
-        }
-        // row 1 of edge_index: its place in the caller's [2, total] is known now (the last chunk's event orders it behind every fill)
-        if (base > 0) HIP_TRY(hipMemcpyAsync(edge_index_out + base, d_ei + cap, (size_t)base * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
-        HIP_TRY(hipStreamSynchronize(cs));
-        *total_edges_out = base;
-        return UGS_OK;
-    };
-    auto drain = [&] { if (cs) (void)hipStreamSynchronize(cs); (void)hipStreamSynchronize(s); };
+    StreamCall sc;
+    sc.dc = dc; sc.G = G; sc.m = m_per_graph; sc.k = k; sc.mode = mode; sc.extra = 0; sc.seed = seed; sc.cap = cap;
+    sc.nodes = nodes; sc.edge_index = edge_index_out; sc.edge_ptr = edge_ptr; sc.sample_ptr = sample_ptr; sc.edge_src = edge_src_global;
+    sc.total_out = total_edges_out;
+    hipStream_t s = dc.stream;
+    auto body = [&](ugs_plan *p) { return stream_rows(p, sc); };
+    auto drain = [&] { if (sc.cs) (void)hipStreamSynchronize(sc.cs); (void)hipStreamSynchronize(s); };
     int rc = UGS_OK;
     if (guess) {
         std::string guess_err;
@@ -2573,9 +2596,35 @@ int ugs_sample_batch_stream(const int64_t *edge_index, int64_t row_stride, int64
         plan_unref(guess);
     } else rc = body(plan);
     if (rc != UGS_OK) drain();                                      // nothing may still read the pool buffers
-    for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
-    pool_put(d_nodes_b); pool_put(d_eptr_b); pool_put(d_loc_b); pool_put(d_edges_b);
+    sc.release();
     if (plan) plan_unref(plan);
+    return rc;
+}
+
+/* sample() of the handle API (reference src/sampler.cpp:91-290) the same way: rows in chunks, copy-out beside the walks. */
+int ugs_sample_stream(int64_t handle, int m_per_graph, int k, int edge_mode, int64_t base_offset, int seed, int64_t edge_capacity,
+                      int64_t *nodes, int64_t *edge_index_out, int64_t *edge_ptr, int64_t *edge_src, int64_t *total_edges_out) {
+    if (edge_mode < 0 || edge_mode > 2) return fail(UGS_E_BAD_MODE, "edge_mode must be one of: 'local', 'flat', 'global'");
+    if (m_per_graph < 0) return fail(UGS_E_BAD_ARG, "m_per_graph must be >= 0");
+    if (edge_capacity < 0 || !edge_ptr || !total_edges_out) return fail(UGS_E_BAD_ARG, "null output pointer or negative edge_capacity");
+    if (m_per_graph > 0 && (!nodes || (edge_capacity > 0 && (!edge_index_out || !edge_src)))) return fail(UGS_E_BAD_ARG, "null output pointer");
+    auto g = lookup(handle);
+    if (!g) return fail(UGS_E_INVALID_HANDLE, "Invalid preproc handle");
+    if (g->n == 0) return fail(UGS_E_NO_ROOTS, "No viable roots available");
+    if (k < 1) return fail(UGS_E_BAD_ARG, "k must be >= 1");
+    if (k > UGS_KMAX) return fail(UGS_E_UNSUPPORTED, "k > 32 is not supported by the HIP sampler");
+    ugs_plan *plan = nullptr;
+    if (int rc = ugs_plan_create_handle(handle, &plan)) return rc;
+    StreamCall sc;
+    if (int rc = device_ctx(sc.dc)) { plan_unref(plan); return rc; }
+    sc.G = plan->G; sc.m = m_per_graph; sc.k = k; sc.mode = edge_mode; sc.extra = edge_mode == UGS_EDGE_GLOBAL ? base_offset : 0; sc.seed = seed;
+    sc.cap = edge_capacity;
+    sc.nodes = nodes; sc.edge_index = edge_index_out; sc.edge_ptr = edge_ptr; sc.sample_ptr = nullptr; sc.edge_src = edge_src;
+    sc.total_out = total_edges_out;
+    const int rc = stream_rows(plan, sc);
+    if (rc != UGS_OK) { if (sc.cs) (void)hipStreamSynchronize(sc.cs); (void)hipStreamSynchronize(sc.dc.stream); }
+    sc.release();
+    plan_unref(plan);
     return rc;
 }
 

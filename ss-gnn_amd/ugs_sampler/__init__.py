@@ -161,8 +161,29 @@ def sample(handle, m_per_graph, k, edge_mode="local", base_offset=0, seed=42, *,
     if edge_mode not in _EDGE_MODES:
         raise RuntimeError("edge_mode must be one of: 'local', 'flat', 'global'")
     _select_device(device, jobs=True)
+    key = ("handle", int(handle), m, k, edge_mode)
+    streamed = device is None and m >= _STREAM_MIN_ROWS and not os.environ.get("UGS_NO_STREAMED_CALL")
+    if streamed and key in _stream_totals and torch.cuda.is_available():     # large host-visible call of a shape seen before (see sample_batch)
+        seen = _stream_totals[key]
+        cap = seen + seen // 50 + 4096
+        opts, _ = _out_opts(None)
+        sizes = [m * k, m + 1, cap, 2 * cap]
+        buf = torch.empty((sum(sizes),), **opts)
+        o1, o2, o3 = sizes[0], sizes[0] + sizes[1], sizes[0] + sizes[1] + sizes[2]
+        base, total = buf.data_ptr(), C.c_int64()
+        rc = lib.ugs_sample_stream(int(handle), m, k, _EDGE_MODES[edge_mode], int(base_offset), seed, cap,
+                                   base, base + 8 * o3, base + 8 * o1, base + 8 * o2, C.byref(total))
+        if rc != UGS_E_CAPACITY:
+            check(rc)
+            t = total.value
+            _stream_totals[key] = max(seen, t)
+            return buf[:o1].view(m, k), buf[o3:o3 + 2 * t].view(2, t), buf[o1:o2], buf[o2:o2 + t]
     job, total = vp(), C.c_int64()
     check(lib.ugs_sample_begin(int(handle), m, k, _EDGE_MODES[edge_mode], int(base_offset), seed, C.byref(job), C.byref(total)))
+    if streamed:
+        if key not in _stream_totals and len(_stream_totals) >= 1024:
+            _stream_totals.clear()
+        _stream_totals[key] = max(_stream_totals.get(key, 0), total.value)
     try:
         opts, on_dev = _out_opts(device)
         nodes, edge_ptr, edge_index, edge_src = _carve(opts, [(m, k), (m + 1,), (2, total.value), (total.value,)])
@@ -233,6 +254,8 @@ def sample_batch(edge_index, ptr, m_per_graph, k, mode="sample", seed=42, *, dev
     check(lib.ugs_sample_batch_begin(p, stride, e, ptr_c.data_ptr(), G, m, k, _BATCH_MODES[mode], seed, C.byref(job), C.byref(total)))
     if device is None and max(G, 0) * m >= _STREAM_MIN_ROWS:
         key = (e, G, m, k, mode)
+        if key not in _stream_totals and len(_stream_totals) >= 1024:      # (a stream of ever-new shapes: forget, the next calls re-learn)
+            _stream_totals.clear()
         _stream_totals[key] = max(_stream_totals.get(key, 0), total.value)
     try:
         opts, on_dev = _out_opts(device)

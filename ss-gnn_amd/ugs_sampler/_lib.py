@@ -37,6 +37,7 @@ def _load():
         "ugs_sample_batch_stream": [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
                                     vp, vp, vp, vp, vp, i64p],
         "ugs_stream_stats": [i64p, i64p],
+        "ugs_sample_stream": [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int64, vp, vp, vp, vp, i64p],
         "ugs_apx_sample_batch": [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, C.c_uint64, C.c_double, vp, i64p],
         "ugs_apx_gpu_sample_batch": [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, C.c_uint64, C.c_double, vp, i64p, vp, vp, C.c_int64],
         "ugs_eps_sample_batch_begin": [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_double,

@@ -894,3 +894,44 @@ def test_streamed_call_equals_the_two_phase_call_and_the_oracle(shape, monkeypat
         assert np.array_equal(a.numpy(), b.numpy())
     cache.close()
     ugs_sampler._stream_totals.clear()
+
+
+def test_streamed_handle_call_equals_the_two_phase_call_and_the_oracle(monkeypatch):
+    """ugs_sample_stream (sample() of the handle API in chunks with the copy-out beside the walks): every edge mode incl. a base offset,
+    chunk sizes that leave a last chunk of one row, against the two-phase call and the CPU oracle; an estimate too small falls back."""
+    import torch
+    import oracle
+    import ugs_sampler
+    rng = np.random.default_rng(11)
+    n, m, k = 2500, 1801, 7
+    ei = np.ascontiguousarray(_er(rng, n, 24))
+    ei_t = torch.from_numpy(ei)
+    h = ugs_sampler.create_preproc(ei_t, n, k)
+    P = oracle.Preproc(ei, n, k)
+    monkeypatch.setattr(ugs_sampler, "_STREAM_MIN_ROWS", 1)
+    ugs_sampler._stream_totals.clear()
+    try:
+        for edge_mode, off, chunk in (("local", 0, 100), ("flat", 0, 1800), ("global", 12345, 601), ("local", 0, 5000)):
+            monkeypatch.setenv("UGS_STREAM_CHUNK_ROWS", str(chunk))
+            monkeypatch.setenv("UGS_NO_STREAMED_CALL", "1")
+            two_phase = ugs_sampler.sample(h, m, k, edge_mode, off, 3)
+            monkeypatch.delenv("UGS_NO_STREAMED_CALL")
+            first = ugs_sampler.sample(h, m, k, edge_mode, off, 3)                     # learns the total
+            key = ("handle", int(h), m, k, edge_mode)
+            assert ugs_sampler._stream_totals[key] >= two_phase[1].shape[1]
+            streamed = ugs_sampler.sample(h, m, k, edge_mode, off, 3)
+            other = ugs_sampler.sample(h, m, k, edge_mode, off, 4)
+            want, want4 = P.sample(m, k, edge_mode, off, 3), P.sample(m, k, edge_mode, off, 4)
+            for name, a, b, c, w, o, w4 in zip(("nodes", "edge_index", "edge_ptr", "edge_src"), two_phase, first, streamed, want, other, want4):
+                assert c.is_contiguous() and c.dtype == torch.int64 and c.is_pinned()
+                assert np.array_equal(a.numpy(), np.asarray(w)) and np.array_equal(b.numpy(), np.asarray(w)), (edge_mode, name)
+                assert np.array_equal(c.numpy(), np.asarray(w)) and np.array_equal(o.numpy(), np.asarray(w4)), (edge_mode, name, "streamed")
+        ugs_sampler._stream_totals[("handle", int(h), m, k, "local")] = 10              # far too small: the two-phase path serves the call
+        again = ugs_sampler.sample(h, m, k, "local", 0, 3)
+        for a, w in zip(again, P.sample(m, k, "local", 0, 3)):
+            assert np.array_equal(a.numpy(), np.asarray(w))
+        assert ugs_sampler._stream_totals[("handle", int(h), m, k, "local")] == again[1].shape[1]
+    finally:
+        P.close()
+        ugs_sampler.destroy_preproc(h)
+        ugs_sampler._stream_totals.clear()
