@@ -47,6 +47,28 @@ for chunk in ((0,) if os.environ.get("UGS_PROBE_ONLY_DEFAULT") else (0, 31250, 6
     ugs_sampler.sample_batch(ei_t, ptr_t, m, k, seed=41)
     out["streamed"]["default(rows/8)" if not chunk else str(chunk)] = timed()
 os.environ.pop("UGS_STREAM_CHUNK_ROWS", None)
+if len(ptr) == 2 and not os.environ.get("UGS_PROBE_ONLY_DEFAULT"):      # one graph: the same job through the handle API (create_preproc + sample)
+    h = ugs_sampler.create_preproc(ei_t, int(ptr[-1]), k)
+
+    def timed_handle():
+        ts = []
+        for r in range(reps):
+            t = time.perf_counter()
+            o = ugs_sampler.sample(h, m, k, "local", 0, 42 + r)
+            ts.append((time.perf_counter() - t) * 1e3)
+            del o
+        ts.sort()
+        return {"median_ms": round(ts[len(ts) // 2], 3), "min_ms": round(ts[0], 3), "max_ms": round(ts[-1], 3), "subgraphs_per_s": round(rows / ts[len(ts) // 2] * 1e3, 1)}
+    os.environ["UGS_NO_STREAMED_CALL"] = "1"
+    want = ugs_sampler.sample(h, m, k, "local", 0, 42)
+    out["handle_two_phase"] = timed_handle()
+    del os.environ["UGS_NO_STREAMED_CALL"]
+    ugs_sampler.sample(h, m, k, "local", 0, 41)
+    got = ugs_sampler.sample(h, m, k, "local", 0, 42)
+    out["handle_streamed_equals_two_phase"] = all(torch.equal(a, b) for a, b in zip(got, want))
+    del got, want
+    out["handle_streamed"] = timed_handle()
+    ugs_sampler.destroy_preproc(h)
 for d in out["streamed"].values():
     d["subgraphs_per_s"] = round(rows / d["median_ms"] * 1e3, 1)
 out["two_phase"]["subgraphs_per_s"] = round(rows / out["two_phase"]["median_ms"] * 1e3, 1)
