@@ -2427,11 +2427,18 @@ int ugs_sample_batch_begin(const int64_t *edge_index, int64_t row_stride, int64_
         int lookup_rc = UGS_OK;
         std::string lookup_err;
         const int dev_tl = t_device; const hipStream_t st_tl = t_job_stream; const bool set_tl = t_job_stream_set;
-        std::thread lookup_thread([&, dev_tl, st_tl, set_tl] {
-            t_device = dev_tl >= 0 ? dev_tl : dc.id; t_job_stream = st_tl; t_job_stream_set = set_tl;
-            lookup_rc = ugs_plan_create_batch(edge_index, row_stride, num_cols, ptr, num_graphs, k, &plan);
-            if (lookup_rc != UGS_OK) lookup_err = t_err;
-        });
+        std::thread lookup_thread;
+        try {
+            lookup_thread = std::thread([&, dev_tl, st_tl, set_tl] {
+                t_device = dev_tl >= 0 ? dev_tl : dc.id; t_job_stream = st_tl; t_job_stream_set = set_tl;
+                lookup_rc = ugs_plan_create_batch(edge_index, row_stride, num_cols, ptr, num_graphs, k, &plan);
+                if (lookup_rc != UGS_OK) lookup_err = t_err;
+            });
+        } catch (...) { plan_unref(guess); guess = nullptr; }          // no thread to be had: look up first, as without a guess
+        if (!guess) {
+            if (int rc = ugs_plan_create_batch(edge_index, row_stride, num_cols, ptr, num_graphs, k, &plan)) return rc;
+            return begin_common(plan, m_per_graph, k, mode, 0, seed, true, job_out, total_edges_out);
+        }
         *job_out = nullptr;
         const int rc = begin_common(guess, m_per_graph, k, mode, 0, seed, true, job_out, total_edges_out);   // (owns the guess's reference)
         lookup_thread.join();
@@ -2570,12 +2577,15 @@ int ugs_sample_batch_stream(const int64_t *edge_index, int64_t row_stride, int64
     std::string lookup_err;
     if (guess) {
         const int dev_tl = t_device; const hipStream_t st_tl = t_job_stream; const bool set_tl = t_job_stream_set;
-        lookup_thread = std::thread([&, dev_tl, st_tl, set_tl] {
-            t_device = dev_tl >= 0 ? dev_tl : dc.id; t_job_stream = st_tl; t_job_stream_set = set_tl;
-            lookup_rc = ugs_plan_create_batch(edge_index, row_stride, num_cols, ptr, num_graphs, k, &plan);
-            if (lookup_rc != UGS_OK) lookup_err = t_err;
-        });
-    } else if (int rc = ugs_plan_create_batch(edge_index, row_stride, num_cols, ptr, num_graphs, k, &plan)) return rc;
+        try {
+            lookup_thread = std::thread([&, dev_tl, st_tl, set_tl] {
+                t_device = dev_tl >= 0 ? dev_tl : dc.id; t_job_stream = st_tl; t_job_stream_set = set_tl;
+                lookup_rc = ugs_plan_create_batch(edge_index, row_stride, num_cols, ptr, num_graphs, k, &plan);
+                if (lookup_rc != UGS_OK) lookup_err = t_err;
+            });
+        } catch (...) { plan_unref(guess); guess = nullptr; }          // no thread to be had: look up first, as without a guess
+    }
+    if (!guess) if (int rc = ugs_plan_create_batch(edge_index, row_stride, num_cols, ptr, num_graphs, k, &plan)) return rc;
     StreamCall sc;
     sc.dc = dc; sc.G = G; sc.m = m_per_graph; sc.k = k; sc.mode = mode; sc.extra = 0; sc.seed = seed; sc.cap = cap;
     sc.nodes = nodes; sc.edge_index = edge_index_out; sc.edge_ptr = edge_ptr; sc.sample_ptr = sample_ptr; sc.edge_src = edge_src_global;
