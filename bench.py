@@ -57,6 +57,8 @@ def parse_args(argv=None):
     ap.add_argument("--dst-rows", default="auto", help="N > 1: the destination's share of the rows.  'auto' (default): measured -- two short local "
                     "calibration rounds in the warm-up (three; each rank's own work per step, no exchange), one all-gather each, then rows in proportion to "
                     "rows per millisecond; 'equal': the equal split; a number w: weight of the destination against 1.0 for every other rank")
+    ap.add_argument("--two-steps", action="store_true", help="N = 1 measurement aid: two steps in flight on two streams (plan + twin), as the N > 1 job "
+                    "does -- the next step's walk fills this one's tail; per-kernel event times then overlap and are not a roofline figure")
     ap.add_argument("--one-stream", action="store_true", help="N > 1: one step at a time (no second stream / buffer set / plan scratch)")
     ap.add_argument("--force-collate", action="store_true", help="run the multi-GPU collation path even with one rank (rehearsal)")
     ap.add_argument("--rehearse", action="store_true", help="N ranks on ONE GPU over gloo (every rank uses cuda:0): exercises the multi-rank control flow "
@@ -215,7 +217,7 @@ class Job:
         self.row_off = ud.shard_offsets(self.total_rows, world, weights)      # the same list on every rank
         self.row_begin, self.row_count = self.row_off[rank], self.row_off[rank + 1] - self.row_off[rank]
         self.use_collate = use_collate
-        self.nsets = 2 if (use_collate and not args.one_stream) else 1     # steps alternate between two streams / buffer sets / plan scratches
+        self.nsets = 2 if ((use_collate or getattr(args, "two_steps", False)) and not args.one_stream) else 1     # steps alternate between two streams / buffer sets / plan scratches
         rc = self.row_count
         self.nodes = [torch.empty((rc, k), dtype=torch.int64, device=dev) for _ in range(self.nsets)]
         self.eptr = [torch.empty((rc + 1,), dtype=torch.int64, device=dev) for _ in range(self.nsets)]
