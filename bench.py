@@ -713,6 +713,9 @@ def summary_block(out, workload):
     hv = d.get("host_visible_subgraphs_per_s")
     s[workload[:2]] = {"dev": m3(out["value"] / 1e6), "hv": m3(hv / 1e6) if hv else None, "ref_k": m3(ref / 1e3) if ref else None,
                        "x_hv": m3(hv / ref) if hv and ref else None}
+    tp = (out.get("drop_in_call") or {}).get("host_visible_two_phase_ms")
+    if tp:                                  # the same call without the streamed copy-out (walks, then fill, then copy): M/s
+        s[workload[:2]]["hv_2ph"] = m3((out["drop_in_call"]["rows"] / (tp * 1e-3)) / 1e6)
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             iss = json.load(f).get(workload, {}).get("issue")
