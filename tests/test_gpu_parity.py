@@ -935,3 +935,52 @@ def test_streamed_handle_call_equals_the_two_phase_call_and_the_oracle(monkeypat
         P.close()
         ugs_sampler.destroy_preproc(h)
         ugs_sampler._stream_totals.clear()
+
+
+def test_streamed_call_edge_cases_vs_oracle():
+    """ugs_sample_batch_stream on the inputs the reference's tests treat specially: no graphs, m = 0, k = 1 (no edges: capacity 0 and
+    null edge buffers are fine), graphs smaller than k (rows of -1), a batch without columns -- against the oracle.  The graph cache is
+    emptied before every call: its key ignores k as the reference's does, and the oracle call starts from a fresh one."""
+    import ctypes as C
+    import torch
+    import oracle
+    import ugs_sampler
+    from ugs_sampler._lib import lib, UGS_E_CAPACITY
+
+    def stream(ei, ptr, m, k, cap, mode=0, seed=5):
+        ei = np.ascontiguousarray(ei.reshape(2, -1))
+        G = len(ptr) - 1
+        B = G * m
+        nodes, eptr, sptr = torch.full((max(B * k, 1),), 7, dtype=torch.int64).pin_memory(), torch.full((B + 1,), 7, dtype=torch.int64).pin_memory(), \
+            torch.full((G + 1,), 7, dtype=torch.int64).pin_memory()
+        eidx, esrc = torch.full((max(2 * cap, 1),), 7, dtype=torch.int64).pin_memory(), torch.full((max(cap, 1),), 7, dtype=torch.int64).pin_memory()
+        t = C.c_int64(-1)
+        ei_t, ptr_t = torch.from_numpy(ei), torch.from_numpy(np.asarray(ptr, dtype=np.int64))
+        rc = lib.ugs_sample_batch_stream(ei_t.data_ptr() if ei.size else None, ei.shape[1], ei.shape[1], ptr_t.data_ptr(), G, m, k, mode, seed, cap,
+                                         nodes.data_ptr(), eidx.data_ptr() if cap else None, eptr.data_ptr(), sptr.data_ptr(),
+                                         esrc.data_ptr() if cap else None, C.byref(t))
+        if rc != 0:
+            return rc, t.value                                            # (a capacity error reports the entries it had reached)
+        return rc, t.value, nodes[:B * k].view(B, k).numpy(), eidx[:2 * max(t.value, 0)].view(2, -1).numpy(), eptr.numpy(), sptr.numpy(), esrc[:max(t.value, 0)].numpy()
+
+    def check(ei, ptr, m, k, cap):
+        ugs_sampler.clear_cache()
+        rc, tot, nodes, eidx, eptr, sptr, esrc = stream(ei, ptr, m, k, cap)
+        assert rc == 0
+        w = [np.asarray(x) for x in oracle.sample_batch(np.ascontiguousarray(ei.reshape(2, -1)), np.asarray(ptr, dtype=np.int64), m, k, "sample", 5)]
+        assert tot == w[1].shape[1]
+        for got, want in zip((nodes, eidx, eptr, sptr, esrc), w):
+            assert np.array_equal(got, want.reshape(got.shape))
+
+    tri = np.array([[0, 1, 2, 3, 4], [1, 2, 0, 4, 3]], dtype=np.int64)                  # a triangle and an edge
+    none = np.zeros((2, 0), dtype=np.int64)
+    check(none, [0], 4, 3, 0)                                                           # no graphs
+    check(tri, [0, 3, 5], 0, 3, 0)                                                      # m = 0
+    check(tri, [0, 3, 5], 9, 1, 0)                                                      # k = 1: nodes only
+    check(tri, [0, 3, 5], 9, 3, 200)                                                    # the second graph is smaller than k: rows of -1
+    check(none, [0, 4], 5, 2, 0)                                                        # a graph without columns
+    check(tri, [0, 3, 5], 9, 2, 200)
+    ugs_sampler.clear_cache()
+    rc, reached = stream(tri, [0, 3, 5], 9, 2, 0)                                       # edges but no room for them
+    assert rc == UGS_E_CAPACITY and reached > 0
+    assert stream(tri, [0, 3, 5], 9, 2, 200, mode=5)[0] != 0 and b"mode must be one of" in lib.ugs_last_error()
