@@ -984,3 +984,48 @@ def test_streamed_call_edge_cases_vs_oracle():
     rc, reached = stream(tri, [0, 3, 5], 9, 2, 0)                                       # edges but no room for them
     assert rc == UGS_E_CAPACITY and reached > 0
     assert stream(tri, [0, 3, 5], 9, 2, 200, mode=5)[0] != 0 and b"mode must be one of" in lib.ugs_last_error()
+
+
+def test_streamed_handle_call_edge_cases_vs_oracle():
+    """ugs_sample_stream on the handle API's special inputs: m = 0, k = 1 (capacity 0, null edge buffers), every edge mode on a small
+    graph, an unknown handle, a bad edge mode, and a capacity too small (the call reports the entries it had reached)."""
+    import ctypes as C
+    import torch
+    import oracle
+    import ugs_sampler
+    from ugs_sampler._lib import lib, UGS_E_CAPACITY
+
+    ei = np.array([[0, 1, 2, 3, 4, 0, 2], [1, 2, 0, 4, 5, 3, 5]], dtype=np.int64)        # a triangle with a tail, six vertices
+    n = 6
+
+    def stream(h, m, k, mode, off, cap, seed=9):
+        nodes, eptr = torch.full((max(m * k, 1),), 7, dtype=torch.int64).pin_memory(), torch.full((m + 1,), 7, dtype=torch.int64).pin_memory()
+        eidx, esrc = torch.full((max(2 * cap, 1),), 7, dtype=torch.int64).pin_memory(), torch.full((max(cap, 1),), 7, dtype=torch.int64).pin_memory()
+        t = C.c_int64(-1)
+        rc = lib.ugs_sample_stream(h, m, k, mode, off, seed, cap, nodes.data_ptr(), eidx.data_ptr() if cap else None, eptr.data_ptr(),
+                                   esrc.data_ptr() if cap else None, C.byref(t))
+        if rc != 0:
+            return rc, t.value
+        return rc, t.value, nodes[:m * k].view(m, k).numpy(), eidx[:2 * t.value].view(2, -1).numpy(), eptr.numpy(), esrc[:t.value].numpy()
+
+    for k in (1, 2, 3, 6):
+        h = ugs_sampler.create_preproc(torch.from_numpy(ei), n, k)
+        P = oracle.Preproc(ei, n, k)
+        try:
+            for name, mode, off in (("local", 0, 0), ("flat", 1, 0), ("global", 2, 777)):
+                for m in (0, 1, 23):
+                    cap = 0 if k == 1 or m == 0 else 2 * m * k * k
+                    rc, tot, *got = stream(h, m, k, mode, off, cap)
+                    assert rc == 0, (k, name, m, lib.ugs_last_error())
+                    want = [np.asarray(x) for x in P.sample(m, k, name, off, 9)]
+                    assert tot == want[1].shape[1]
+                    for g, w in zip(got, want):
+                        assert np.array_equal(g, w.reshape(g.shape)), (k, name, m)
+            if k == 3:
+                rc, reached = stream(h, 23, k, 0, 0, 1)
+                assert rc == UGS_E_CAPACITY and reached > 1
+                assert stream(h, 23, k, 4, 0, 500)[0] != 0 and b"edge_mode must be one of" in lib.ugs_last_error()
+        finally:
+            P.close()
+            ugs_sampler.destroy_preproc(h)
+    assert stream(987654321, 4, 2, 0, 0, 100)[0] != 0 and b"Invalid preproc handle" in lib.ugs_last_error()
