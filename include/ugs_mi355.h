@@ -108,8 +108,9 @@ int ugs_job_cancel(ugs_job *job);
  * PCIe on a second stream while the next chunk walks (the two-phase call copies only after the last walk).  On return
  * *total_edges_out = total, edge_index_out holds [2, total] CONTIGUOUSLY at its start (row 1 begins at edge_index_out + total) and
  * edge_src_global[total].  edge_capacity is the caller's estimate (e.g. the total of an earlier call on the same batch plus a
- * margin); a call that needs more returns UGS_E_CAPACITY with the buffers' contents undefined -- repeat it through
- * ugs_sample_batch_begin / _finish.  UGS_STREAM_CHUNK_ROWS overrides the chunk size (default: an eighth of the rows, >= 65536). */
+ * margin); a call that needs more returns UGS_E_CAPACITY with the buffers' contents undefined and *total_edges_out = the entries
+ * reached when the room ran out (> edge_capacity, a lower bound on the total) -- repeat it through ugs_sample_batch_begin / _finish.
+ * k = 1 or m_per_graph = 0 produce no entries: edge_capacity 0 with null edge buffers is accepted.  UGS_STREAM_CHUNK_ROWS overrides the chunk size (default: an eighth of the rows, >= 65536). */
 int ugs_sample_batch_stream(const int64_t *edge_index, int64_t row_stride, int64_t num_cols, const int64_t *ptr,
                             int64_t num_graphs, int m_per_graph, int k, int mode, int seed, int64_t edge_capacity,
                             int64_t *nodes, int64_t *edge_index_out, int64_t *edge_ptr, int64_t *sample_ptr,
